@@ -1,0 +1,138 @@
+"""ORACLE — test infrastructure only.  Never imported by the product package.
+
+CPU restatement (numpy / torch float32+float64) of the similarity-search half of the hot path:
+
+* row cosine           torch ``F.cosine_similarity`` as called at
+                       /root/reference/src/pipeline/search_pipeline.py:77   (eps semantics: SURVEY.md §8 A7)
+* dense cosine matrix  ``cos_sim``  /root/reference/src/utils/metrics.py:81-101 (no eps: zero rows -> NaN)
+* per-query top-k      ``torch.topk(scores, k, largest=True)`` search_pipeline.py:78, with the tie rule the
+                       reference leaves undefined fixed as: score descending, then index ascending
+* the search loop      search_pipeline.py:60-89 (intended semantics)
+
+torch (the pinned third-party dependency, requirements.txt:4 torch==1.6.0; installed 2.10.0) holds the
+arithmetic; its published semantics are restated here in numpy.  Pinned against golden vectors produced in
+the build container by the reference's own ``cos_sim`` and by torch ``cosine_similarity``/``topk``
+(tools/make_golden.py -> tests/golden/search_*.npz); see tests/test_oracle_golden.py.
+
+Canonical score.  The GPU path scores bf16 rows with MFMA (fp32 accumulate, hardware summation order) to
+*select candidates* and then re-scores the few survivors in a fixed order so results are reproducible bit
+for bit: products of two bf16 values are exact in float64, they are accumulated in float64 in index order
+j = 0..d-1 and the sum is rounded once to float32.  ``canonical_scores`` is that definition.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return np.where(np.isnan(x), x, r.astype(np.uint32).view(np.float32)).astype(np.float32)
+
+
+def l2_normalize(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """x / max(||x||, eps) in float32 (row-wise): the per-operand clamp of torch>=1.12
+    cosine_similarity; a zero row stays zero, so its cosine with anything is 0."""
+    x = np.asarray(x, dtype=np.float32)
+    n = np.sqrt((x.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32)
+    return (x / np.maximum(n, np.float32(eps))).astype(np.float32)
+
+
+def cosine_similarity_rows(x: np.ndarray, y: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """F.cosine_similarity(x, y, dim=-1) for x,y [N,H] float32 (search_pipeline.py:77)."""
+    x = np.asarray(x, dtype=np.float32)
+    y = np.asarray(y, dtype=np.float32)
+    dot = (x.astype(np.float64) * y.astype(np.float64)).sum(-1)
+    nx = np.maximum(np.sqrt((x.astype(np.float64) ** 2).sum(-1)), eps)
+    ny = np.maximum(np.sqrt((y.astype(np.float64) ** 2).sum(-1)), eps)
+    return (dot / (nx * ny)).astype(np.float32)
+
+
+def cos_sim(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """metrics.py:81-101: a/||a|| @ (b/||b||)^T, 1-D inputs promoted to one row, no eps."""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[None, :]
+    if b.ndim == 1:
+        b = b[None, :]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        an = a / np.linalg.norm(a, axis=-1)[:, None]
+        bn = b / np.linalg.norm(b, axis=-1)[:, None]
+        return (an.astype(np.float64) @ bn.astype(np.float64).T).astype(np.float32)
+
+
+def canonical_scores(eq: np.ndarray, ec: np.ndarray) -> np.ndarray:
+    """[Q,N] float32: sequential float64 accumulation over j = 0..d-1 of eq[:,j]*ec[:,j], one final
+    rounding to float32.  Inputs are the (bf16-exact) normalised rows."""
+    eq = np.asarray(eq, dtype=np.float64)
+    ec = np.asarray(ec, dtype=np.float64)
+    acc = np.zeros((eq.shape[0], ec.shape[0]), dtype=np.float64)
+    for j in range(eq.shape[1]):
+        acc += eq[:, j:j + 1] * ec[None, :, j]
+    return acc.astype(np.float32)
+
+
+def canonical_scores_pairs(eq: np.ndarray, ec: np.ndarray, qi: np.ndarray, ci: np.ndarray) -> np.ndarray:
+    """canonical score of selected (query, corpus) index pairs."""
+    a = np.asarray(eq, dtype=np.float64)[qi]
+    b = np.asarray(ec, dtype=np.float64)[ci]
+    acc = np.zeros(a.shape[0], dtype=np.float64)
+    for j in range(a.shape[1]):
+        acc += a[:, j] * b[:, j]
+    return acc.astype(np.float32)
+
+
+def topk_rows(scores: np.ndarray, k: int):
+    """k largest per row, sorted by (score desc, index asc).  Returns (values [Q,k] f32, idx [Q,k] i64)."""
+    scores = np.asarray(scores, dtype=np.float32)
+    Q, N = scores.shape
+    k = min(k, N)
+    idx = np.empty((Q, k), dtype=np.int64)
+    for q in range(Q):
+        s = scores[q]
+        if N > 4 * k + 64:
+            kth = np.partition(s, N - k)[N - k]
+            cand = np.nonzero(s >= kth)[0]
+        else:
+            cand = np.arange(N)
+        order = np.lexsort((cand, -s[cand].astype(np.float64)))
+        idx[q] = cand[order[:k]]
+    return np.take_along_axis(scores, idx, 1), idx
+
+
+def cosine_topk(eq: np.ndarray, ec: np.ndarray, k: int, idx_offset: int = 0, block: int = 64):
+    """Exact top-k of canonical scores of every query row against every corpus row."""
+    vals, idxs = [], []
+    for s in range(0, eq.shape[0], block):
+        v, i = topk_rows(canonical_scores(eq[s:s + block], ec), k)
+        vals.append(v)
+        idxs.append(i + idx_offset)
+    return np.concatenate(vals), np.concatenate(idxs)
+
+
+def merge_topk(values, indices, k: int):
+    """Merge per-shard (values [Q,k_i], global indices [Q,k_i]) lists: (score desc, index asc)."""
+    v = np.concatenate(values, axis=1)
+    i = np.concatenate(indices, axis=1)
+    out_v = np.empty((v.shape[0], min(k, v.shape[1])), dtype=np.float32)
+    out_i = np.empty(out_v.shape, dtype=np.int64)
+    for q in range(v.shape[0]):
+        order = np.lexsort((i[q], -v[q].astype(np.float64)))[:out_v.shape[1]]
+        out_v[q], out_i[q] = v[q][order], i[q][order]
+    return out_v, out_i
+
+
+def mining_search(query_emb: np.ndarray, corpus_emb: np.ndarray, k: int, chunk: int):
+    """search_pipeline.py:60-89 as intended: for each corpus chunk, each query row is
+    scored against every chunk row with cosine_similarity and the k best are kept; chunks are merged.
+    Inputs float32 un-normalised embeddings; scoring on bf16-rounded unit rows like the GPU path."""
+    qn = bf16_round(l2_normalize(query_emb))
+    vs, ix = [], []
+    for s in range(0, corpus_emb.shape[0], chunk):
+        cn = bf16_round(l2_normalize(corpus_emb[s:s + chunk]))
+        v, i = cosine_topk(qn, cn, k, idx_offset=s)
+        vs.append(v)
+        ix.append(i)
+    return merge_topk(vs, ix, k)

@@ -1,0 +1,140 @@
+/*
+ * tsim.h — C ABI of libtsim.so, the MI355X (gfx950) embed-and-search engine.
+ *
+ * The reference (cr1m5onk1ng/text_similarity) has no FFI of its own: its boundary for this path is a
+ * Python API whose arithmetic lives in torch / transformers.  Each entry point below replaces one of
+ * those call sites; the Python classes in text_similarity_amd/ keep the reference's names and
+ * signatures and reach these functions through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the caller owns all buffers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); calls only enqueue
+ *     work on it, they never synchronise and never allocate device memory (except tsim_encoder_create);
+ *   - return value 0 = ok, otherwise a TSIM_E* code; tsim_last_error() gives the message for the calling
+ *     thread;
+ *   - "bf16 rows" are row-major uint16 bfloat16 with a row stride of `ld` elements, ld a multiple of 8
+ *     and every row 16-byte aligned; tsim_pad_dim(d) is the stride the engine itself produces.
+ */
+#ifndef TSIM_H
+#define TSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSIM_OK 0
+#define TSIM_EINVAL 1      /* bad argument (shape, alignment, unsupported size) */
+#define TSIM_EHIP 2        /* a HIP runtime call failed */
+#define TSIM_ENOMEM 3      /* workspace too small / allocation failed */
+#define TSIM_EUNSUPPORTED 4
+
+#define TSIM_F32 0
+#define TSIM_BF16 1
+
+#define TSIM_ARCH_BERT 0
+#define TSIM_ARCH_MPNET 1
+
+int tsim_version(void);
+const char *tsim_last_error(void);
+
+/* Row stride (elements) of the engine's internal bf16 embedding matrices for an embedding width d:
+ * the smallest supported kernel width >= d (128, 256, 384, 512, 768 or 1024); 0 if d > 1024. */
+int tsim_pad_dim(int d);
+
+/* ---------------------------------------------------------------------------------------------
+ * A7  F.cosine_similarity operand preparation   /root/reference/src/pipeline/search_pipeline.py:77
+ * out[r, :d] = bf16( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0.
+ * torch divides each operand by max(norm, eps) with eps = 1e-8; a zero row stays zero, so its score
+ * against anything is 0.  x_dtype is TSIM_F32 or TSIM_BF16, ld_in its row stride in elements. */
+int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in,
+                     void *out_bf16, int ld_out, float eps, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A6/A7/A9  the per-query loop `expand_as -> F.cosine_similarity -> torch.topk`
+ *           /root/reference/src/pipeline/search_pipeline.py:73-78, fused.
+ * eq [Q, ld] and ec [N, ld] are L2-normalised bf16 rows (tsim_l2norm_rows).  For every query the k
+ * corpus rows with the largest inner product are returned, ordered by (score descending, index
+ * ascending) — the tie rule torch.topk leaves undefined.  The N x Q score matrix is never written:
+ * MFMA scores live in registers, survivors go through per-lane queues in LDS.  Candidates are then
+ * re-scored in a fixed order (float64 accumulation over j = 0..d-1, one rounding to float32) so scores
+ * and indices are reproducible bit for bit (oracle/search_ref.py canonical_scores).
+ * out_scores [Q, k] float32, out_idx [Q, k] int64 = local row index + idx_offset (-1 / -inf when the
+ * corpus has fewer than k rows).  k <= 28.  workspace: tsim_cosine_topk_workspace_bytes(Q, N, k). */
+size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k);
+int tsim_cosine_topk(const void *eq_bf16, int64_t Q, const void *ec_bf16, int64_t N, int d, int ld,
+                     int k, float *out_scores, int64_t *out_idx, int64_t idx_offset,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Merge `nlists` sorted candidate lists per query (the per-shard results of tsim_cosine_topk on the
+ * shards of a partitioned corpus, or the per-chunk results of search_pipeline.py:60 `corpus_chunk_size`
+ * chunking): scores/idx are [nlists, Q, k_in]; output [Q, k_out] by (score desc, index asc);
+ * entries with idx < 0 are ignored. */
+int tsim_topk_merge(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in,
+                    int k_out, float *out_scores, int64_t *out_idx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A8  cos_sim(a, b)   /root/reference/src/utils/metrics.py:81-101
+ * out[i, j] = <a_i/||a_i||, b_j/||b_j||> in float32, dense [Na, Nb]; no eps (a zero row gives NaN,
+ * as in the reference).  For evaluation-sized inputs; the search path never materialises this. */
+int tsim_cos_sim(const float *a, int64_t na, const float *b, int64_t nb, int d, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4  AvgPoolingStrategy.forward   /root/reference/src/modules/modules.py:158-171
+ *     (== OnnxSentenceTransformerWrapper.forward, src/models/sentence_encoder.py:35-38)
+ * out[b, :] = sum_s hidden[b, s, :] * mask[b, s] / max(sum_s mask[b, s], 1e-9); hidden is float32 or bf16
+ * [B, S, H] contiguous, mask int32 [B, S]; out float32 [B, H]. */
+int tsim_mean_pool(const void *hidden, int hidden_dtype, const int32_t *mask, int64_t B, int S, int H,
+                   float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3  context_embedder(**features)[0]  — the HF AutoModel forward the reference calls at
+ *     /root/reference/src/models/sentence_encoder.py:33,107-108,118 (layer arithmetic:
+ *     src/models/bert_of_theseus.py:185-211, 244-336, 346-350, 411-414, 424-428), followed by A4.
+ */
+typedef struct tsim_encoder tsim_encoder;
+
+typedef struct tsim_encoder_config {
+    int32_t arch;          /* TSIM_ARCH_BERT | TSIM_ARCH_MPNET */
+    int32_t num_layers, hidden, heads, ffn, vocab, max_pos;
+    int32_t pad_id;        /* MPNet: position ids skip tokens equal to pad_id */
+    int32_t rel_buckets;   /* MPNet relative-position buckets (32) */
+    float ln_eps;
+    int32_t max_tokens;    /* capacity of the activation workspace, in packed tokens per call */
+    int32_t max_seqs;      /* capacity in sequences per call */
+} tsim_encoder_config;
+
+/* Per-layer weights, all HOST pointers to float32 in torch nn.Linear layout [out, in]; the engine
+ * converts to bf16 and uploads.  rel_bias_host is [rel_buckets, heads] or NULL for BERT. */
+typedef struct tsim_layer_weights_host {
+    const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo, *ln1_g, *ln1_b;
+    const float *w1, *b1, *w2, *b2, *ln2_g, *ln2_b;
+} tsim_layer_weights_host;
+
+typedef struct tsim_encoder_weights_host {
+    const float *word_emb, *pos_emb, *type_emb /* row 0 is added; NULL for MPNet */, *emb_ln_g, *emb_ln_b;
+    const float *rel_bias;
+    const tsim_layer_weights_host *layers;
+} tsim_encoder_weights_host;
+
+int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_encoder_weights_host *w,
+                        tsim_encoder **out);
+void tsim_encoder_destroy(tsim_encoder *enc);
+
+/* Forward on PACKED tokens (no padding work): token t of sequence b lives at cu_seqlens[b] <= t <
+ * cu_seqlens[b+1]; tok_ids/tok_pos int32 [T] (tok_pos = position-embedding row, tok_col = column of the
+ * token in the padded batch, used for MPNet's relative bias; pass tok_col = NULL to use tok_pos).
+ * Outputs (either may be NULL): pooled_f32 [B, hidden] = masked mean-pool (A4), un-normalised like the
+ * reference's encode_text; unit_bf16 [B, ld_unit] = L2-normalised bf16 rows ready for tsim_cosine_topk;
+ * last_hidden_bf16 [T, hidden] for tests. */
+int tsim_encoder_forward(tsim_encoder *enc, const int32_t *tok_ids, const int32_t *tok_pos,
+                         const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
+                         int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit,
+                         void *last_hidden_bf16, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSIM_H */

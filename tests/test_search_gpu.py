@@ -1,0 +1,154 @@
+"""GPU parity of the search half of the hot path against the oracle (bit-exact: scores and indices).
+Every call goes through the C ABI of libtsim.so."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import search_ref
+from text_similarity_amd import ops, presets
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _unit_dev(x_f32_unit_bf16exact: np.ndarray, d: int):
+    """upload bf16-exact unit rows as the padded bf16 matrix the kernels consume"""
+    ld = ops.pad_dim(d)
+    t = torch.zeros((x_f32_unit_bf16exact.shape[0], ld), dtype=torch.bfloat16)
+    t[:, :d] = torch.from_numpy(x_f32_unit_bf16exact).to(torch.bfloat16)
+    return t.to(DEV)
+
+
+def _check_exact(q, c, k, idx_offset=0):
+    d = q.shape[1]
+    s, i = ops.cosine_topk(_unit_dev(q, d), _unit_dev(c, d), d, k, idx_offset)
+    torch.cuda.synchronize()
+    rs, ri = search_ref.cosine_topk(q, c, k, idx_offset)
+    kk = rs.shape[1]
+    np.testing.assert_array_equal(i.cpu().numpy()[:, :kk], ri)
+    np.testing.assert_array_equal(s.cpu().numpy()[:, :kk], rs)
+    if kk < k:  # corpus smaller than k: padded with -1 / -inf
+        assert (i.cpu().numpy()[:, kk:] == -1).all()
+        assert np.isneginf(s.cpu().numpy()[:, kk:]).all()
+
+
+def test_golden_topk_fixture_with_duplicates():
+    g = golden("search_topk.npz")
+    for k in (1, 3, 10):
+        _check_exact(g["queries"], g["corpus"], k)
+    s, i = ops.cosine_topk(_unit_dev(g["queries"], 384), _unit_dev(g["corpus"], 384), 384, 10)
+    assert i[0, :4].tolist() == [7, 40, 41, 200]           # tie rule: equal scores -> lower index first
+    np.testing.assert_allclose(s.cpu().numpy(), g["loop_top10_values"], rtol=0, atol=1e-3)  # north_star tolerance
+
+
+@pytest.mark.parametrize("Q,N,d,k", [
+    (70, 5000, 384, 10),      # ragged Q (not a multiple of 32), N not a multiple of 32
+    (300, 20011, 384, 10),    # two query blocks
+    (33, 777, 64, 5),         # d padded 64 -> 128
+    (17, 4097, 768, 10),      # 4-wave variant
+    (5, 40, 384, 12),         # tiny corpus
+    (9, 2000, 256, 20),       # KL = 32 lists
+    (64, 33000, 384, 1),
+])
+def test_random_exact(Q, N, d, k):
+    q = presets.synthetic_embeddings(Q, d, f"tq/{Q}/{N}/{d}")
+    c = presets.synthetic_embeddings(N, d, f"tc/{Q}/{N}/{d}")
+    _check_exact(q, c, k, idx_offset=123456789012)
+
+
+def test_corpus_smaller_than_k():
+    q = presets.synthetic_embeddings(3, 384, "small/q")
+    c = presets.synthetic_embeddings(7, 384, "small/c")
+    _check_exact(q, c, 10)
+
+
+def test_many_duplicates_and_zero_rows():
+    c = presets.synthetic_embeddings(3000, 384, "dup/c")
+    c[100:160] = c[5]            # 61 identical rows: more than the candidate list holds
+    c[2000] = 0.0                # zero row -> score exactly 0 (A7 semantics)
+    q = presets.synthetic_embeddings(40, 384, "dup/q")
+    q[0] = c[5]
+    q[1] = 0.0                   # zero query: every score 0 -> the k lowest indices
+    _check_exact(q, c, 10)
+    s, i = ops.cosine_topk(_unit_dev(q, 384), _unit_dev(c, 384), 384, 10)
+    assert i[0].tolist() == [5] + list(range(100, 109))
+    assert i[1].tolist() == list(range(10)) and (s[1] == 0).all()
+
+
+def test_anisotropic_scores_near_ties():
+    # rows = common direction + small noise: all cosines ~0.99, gaps ~1e-4 (random-weight encoders look like this)
+    base = presets.normal("aniso/base", 384)
+    c = base[None, :] + 0.05 * presets.normal("aniso/c", 6000 * 384).reshape(6000, 384)
+    q = base[None, :] + 0.05 * presets.normal("aniso/q", 50 * 384).reshape(50, 384)
+    cu = search_ref.bf16_round(search_ref.l2_normalize(c))
+    qu = search_ref.bf16_round(search_ref.l2_normalize(q))
+    _check_exact(qu, cu, 10)
+
+
+def test_self_search_full_size_properties():
+    """N = 1M x 384 (BASELINE.json size): properties that need no O(N^2) oracle —
+    a row's best match is itself with score ||row||^2, lists are sorted, sampled queries match the oracle."""
+    N, d, Q = 1_000_000, 384, 512
+    g = torch.Generator(device=DEV).manual_seed(4321)
+    x = torch.randn((N, d), generator=g, device=DEV, dtype=torch.float32)
+    unit = ops.l2norm_rows(x)
+    rows = torch.arange(0, N, N // Q, device=DEV)[:Q]
+    s, i = ops.cosine_topk(unit[rows].contiguous(), unit, d, 10)
+    torch.cuda.synchronize()
+    assert (i[:, 0] == rows).all()
+    self_dot = (unit[rows].double() ** 2).sum(1).float()
+    assert torch.equal(s[:, 0], self_dot)
+    assert (s[:, :-1] >= s[:, 1:]).all()
+    # oracle on 4 sampled queries against the whole corpus
+    un = unit[:, :d].float().cpu().numpy()
+    sel = [0, 101, 333, 511]
+    rs, ri = search_ref.cosine_topk(un[rows.cpu().numpy()[sel]], un, 10)
+    np.testing.assert_array_equal(i.cpu().numpy()[sel], ri)
+    np.testing.assert_array_equal(s.cpu().numpy()[sel], rs)
+
+
+def test_l2norm_rows_matches_oracle():
+    x = presets.normal("l2/x", 1000 * 384).reshape(1000, 384) * 3.0
+    x[7] = 0.0
+    u = ops.l2norm_rows(torch.from_numpy(x).to(DEV))
+    torch.cuda.synchronize()
+    got = u[:, :384].float().cpu().numpy()
+    ref = search_ref.bf16_round(search_ref.l2_normalize(x))
+    ulp = np.abs(ref) * 2.0 ** -7 + 1e-30
+    assert (np.abs(got - ref) <= ulp).all()           # at most one bf16 ulp (norm summed in a different order)
+    assert (got != ref).mean() < 1e-3
+    assert (got[7] == 0).all() and (u[:, 384:] == 0).all()
+    xb = torch.from_numpy(x).to(torch.bfloat16).to(DEV)
+    ub = ops.l2norm_rows(xb)
+    refb = search_ref.bf16_round(search_ref.l2_normalize(xb.float().cpu().numpy()))
+    assert (np.abs(ub[:, :384].float().cpu().numpy() - refb) <= np.abs(refb) * 2.0 ** -7 + 1e-30).all()
+
+
+def test_topk_merge_matches_unsharded():
+    q = presets.synthetic_embeddings(50, 384, "mg/q")
+    c = presets.synthetic_embeddings(9000, 384, "mg/c")
+    c[8000] = c[10]
+    qd, cd = _unit_dev(q, 384), _unit_dev(c, 384)
+    full_s, full_i = ops.cosine_topk(qd, cd, 384, 10)
+    ss, ii = [], []
+    for lo in range(0, 9000, 2300):
+        s, i = ops.cosine_topk(qd, cd[lo:lo + 2300].contiguous(), 384, 10, idx_offset=lo)
+        ss.append(s)
+        ii.append(i)
+    ms, mi = ops.topk_merge(ss, ii, 10)
+    assert torch.equal(mi, full_i) and torch.equal(ms, full_s)
+    rs, ri = search_ref.merge_topk([s.cpu().numpy() for s in ss], [i.cpu().numpy() for i in ii], 10)
+    np.testing.assert_array_equal(mi.cpu().numpy(), ri)
+
+
+def test_cos_sim_dense_and_mean_pool_goldens():
+    g = golden("search_cos.npz")
+    out = ops.cos_sim_dense(torch.from_numpy(g["a"]).to(DEV), torch.from_numpy(g["b"]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(out, g["cos_sim"], rtol=0, atol=1e-6)
+    z = ops.cos_sim_dense(torch.from_numpy(g["a"]).to(DEV), torch.from_numpy(g["b_zero"]).to(DEV)).cpu().numpy()
+    assert np.isnan(z[:, 5]).all() and np.array_equal(np.isnan(z), np.isnan(g["cos_sim_zero"]))
+    p = golden("pool_edge.npz")
+    got = ops.mean_pool(torch.from_numpy(p["hidden"]).to(DEV), torch.from_numpy(p["attention_mask"]).to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), p["pooled"], rtol=0, atol=1e-6)
+    assert (got[2] == 0).all()   # all-zero mask row

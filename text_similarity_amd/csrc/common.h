@@ -1,0 +1,72 @@
+// Internal helpers shared by the HIP translation units of libtsim.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/tsim.h"
+
+namespace tsim {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint16_t bf16_t;  // storage type of a bfloat16 element
+
+constexpr int WAVE = 64;
+
+void set_error(const std::string &msg);
+int fail(int code, const char *fmt, ...);
+
+#define TSIM_HIP_CHECK(expr)                                                                      \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return ::tsim::fail(TSIM_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define TSIM_REQUIRE(cond, ...)                                   \
+    do {                                                          \
+        if (!(cond)) return ::tsim::fail(TSIM_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even float -> bf16 bits; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and
+// keeps NaN a NaN (MI355X_MICROARCH.md "Correctness boundaries").
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+}  // namespace tsim

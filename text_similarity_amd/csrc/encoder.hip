@@ -1,0 +1,686 @@
+// Transformer encoder forward for gfx950 (MI355X) on PACKED tokens: BERT and MPNet families.
+//
+// Replaces `context_embedder(**features)[0]` + mean-pool of the reference
+// (/root/reference/src/models/sentence_encoder.py:33-38; layer arithmetic as stated in
+// /root/reference/src/models/bert_of_theseus.py:185-211 embeddings, :244-336 attention,
+// :346-350 / :411-414 / :424-428 projections + residual LayerNorm + GELU).
+//
+// Layout in HBM (per encoder handle): activations are [tokens, features] bf16 row-major over the packed
+// token axis (no padding rows between sequences; the token axis is rounded up to 128 rows of slack):
+//   x0, x1 [Tp, H]   residual stream (LayerNorm outputs)      qkv [Tp, 3H]   fused Q|K|V projections
+//   ctx    [Tp, H]   attention output                         h1  [Tp, F]    GELU(FFN1)
+// Weights bf16 in nn.Linear layout [out, in] (K contiguous for both GEMM operands); embedding tables,
+// biases and LayerNorm parameters float32.
+#include <math.h>
+
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace tsim {
+
+// =====================================================================================================
+// embeddings: x[t] = LayerNorm(word[id] + pos[pos_id] (+ type[0]))        one wave per token, fp32 math
+// HBM-bound: reads 2-3 rows of H floats, writes H bf16.
+// =====================================================================================================
+template <int VPL>  // values per lane = H / 64
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict__ ids,
+                                                       const int32_t *__restrict__ pos,
+                                                       const float *__restrict__ word,
+                                                       const float *__restrict__ pos_emb,
+                                                       const float *__restrict__ type0,
+                                                       const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float eps, int T, int H,
+                                                       bf16_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float *w = word + (int64_t)ids[t] * H;
+    const float *p = pos_emb + (int64_t)pos[t] * H;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int j = lane + i * 64;
+        float a = w[j];
+        if (type0) a += type0[j];   // HF order: (word + token_type) + position
+        a += p[j];
+        v[i] = a;
+        s += a;
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float dlt = v[i] - mean;
+        q = fmaf(dlt, dlt, q);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int j = lane + i * 64;
+        out[(int64_t)t * H + j] = f32_to_bf16((v[i] - mean) * rstd * gamma[j] + beta[j]);
+    }
+}
+
+// =====================================================================================================
+// GEMM  out[m, n] = epilogue( sum_k X[m,k] * W[n,k] + bias[n] )          bf16 in, fp32 accumulate (MFMA)
+//
+// MFMA orientation: A = W tile (rows = output features), B = X tile (columns = tokens), so a lane owns
+// ONE token (column lane&31) and 16 features per 32x32 tile.  Row-wise epilogues (LayerNorm statistics,
+// packed stores of 4 consecutive features) then need almost no cross-lane traffic.
+// Staging: both operands are K-contiguous; tiles stream HBM/L2 -> LDS with global_load_lds_dwordx4 into
+// a 2-stage ring (one barrier per K-step: wait -> barrier -> issue next -> compute).  LDS image: rows of
+// BK*2 bytes packed into 256-byte super-rows, 16-byte slot index XORed with (super-row & 15) so that the
+// ds_read_b128 of a fragment (32 lanes = 32 rows, same K chunk) is bank-conflict free; the permutation is
+// applied on the SOURCE address because LDS-DMA writes lane-linearly.
+// Epilogues: BIAS | BIAS+GELU(erf) | BIAS+RESIDUAL+LAYERNORM (requires BN == N: a workgroup owns whole rows).
+// Roofline: MFMA-bound when K is large; at K = 384 (MiniLM) 288 FLOP per byte moved, i.e. at the
+// HBM/MFMA balance point, so operand reuse through L2 (XCD-aware tile order) matters.
+// =====================================================================================================
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2 };
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output
+    // resolution).  ~14 VALU ops against ~30 for erff().
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __expf(-z * z);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    const float erfv = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erfv);
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+constexpr int gemm_lds_bytes() {
+    return 2 * (BM + BN) * BK * 2;
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
+    const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+    const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MT = TM / 32, NT = TN / 32;
+    constexpr int RB = BK * 2;       // bytes per tile row
+    constexpr int CPR = RB / 16;     // 16-byte chunks per row
+    constexpr int RPS = 256 / RB;    // rows per 256-byte super-row
+    constexpr int X_BYTES = BM * RB, W_BYTES = BN * RB, STAGE = X_BYTES + W_BYTES;
+    constexpr int PIECES = STAGE / 1024, XPIECES = X_BYTES / 1024;
+    constexpr int KSTEPS = BK / 16;
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && X_BYTES % 1024 == 0 && W_BYTES % 1024 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int r = lane & 31, h = lane >> 5;
+
+    // tile order: the ntiles feature tiles of one token tile share blockIdx%8, i.e. one XCD's L2 (speed only)
+    const int b = blockIdx.x, xcd = b & 7, jj = b >> 3;
+    const int nt_id = jj % ntiles;
+    const int mt_id = (jj / ntiles) * 8 + xcd;
+    if (mt_id >= mtiles) return;
+    const int m0 = mt_id * BM, n0 = nt_id * BN;
+
+    // ---- LDS-DMA source descriptors (per piece handled by this wave)
+    auto issue = [&](int kt, int stage) {
+        for (int p = wave; p < PIECES; p += NW) {
+            const bool isx = p < XPIECES;
+            const int sl = (isx ? p : p - XPIECES) * 64 + lane;
+            const int sr = sl >> 4, chp = sl & 15;
+            const int ch = chp ^ (sr & 15);
+            const int row = sr * RPS + ch / CPR, c = ch % CPR;
+            const bf16_t *base = isx ? X + (int64_t)(m0 + row) * K : W + (int64_t)(n0 + row) * K;
+            const char *src = reinterpret_cast<const char *>(base + kt * BK) + c * 16;
+            glds16(src, smem + stage * STAGE + p * 1024);
+        }
+    };
+    // fragment address inside a region for tile row `row`, k-step s, lane half h
+    auto frag_off = [&](int row, int s) {
+        const int sr = row / RPS;
+        const int ch = (row % RPS) * CPR + 2 * s + h;
+        return sr * 256 + ((ch ^ (sr & 15)) << 4);
+    };
+
+    f32x16 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+    const int nk = K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // tile kt landed for everyone; everyone finished reading tile kt-1
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char *xs = smem + (kt & 1) * STAGE;
+        const char *ws = xs + X_BYTES;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            bf16x8 bx[MT], aw[NT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                bx[j] = *reinterpret_cast<const bf16x8 *>(xs + frag_off(wm * TM + j * 32 + r, s));
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                aw[i] = *reinterpret_cast<const bf16x8 *>(ws + frag_off(wn * TN + i * 32 + r, s));
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[i], bx[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  acc[i][j][g]: feature n = n0 + wn*TN + i*32 + (g&3) + 8*(g>>2) + 4*h, token m = m0 + wm*TM + j*32 + r
+    const int nbase = n0 + wn * TN + 4 * h;
+    const int mbase = m0 + wm * TM + r;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = nbase + i * 32 + 8 * gq;
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                acc[i][j][4 * gq + 0] += bv.x;
+                acc[i][j][4 * gq + 1] += bv.y;
+                acc[i][j][4 * gq + 2] += bv.z;
+                acc[i][j][4 * gq + 3] += bv.w;
+            }
+        }
+
+    if constexpr (EPI == EPI_RES_LN) {
+        // residual add, then LayerNorm over the N = BN features of each token (two-pass, fp32)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int64_t m = mbase + j * 32;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = nbase + i * 32 + 8 * gq;
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(res + m * N + n);
+                    acc[i][j][4 * gq + 0] += __uint_as_float(rv.x << 16);
+                    acc[i][j][4 * gq + 1] += __uint_as_float(rv.x & 0xffff0000u);
+                    acc[i][j][4 * gq + 2] += __uint_as_float(rv.y << 16);
+                    acc[i][j][4 * gq + 3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+        }
+        float *red = reinterpret_cast<float *>(smem);  // [WAVES_N][BM] partial sums (staging LDS is free now)
+        float mean[MT], rstd[MT];
+        __builtin_amdgcn_s_barrier();  // all waves are past their last fragment read
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const float v = pass == 0 ? acc[i][j][g] : (acc[i][j][g] - mean[j]) * (acc[i][j][g] - mean[j]);
+                        s += v;
+                    }
+                s += __shfl_xor(s, 32, 64);
+                if (h == 0) red[(pass * WAVES_N + wn) * BM + wm * TM + j * 32 + r] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_N; ++w) s += red[(pass * WAVES_N + w) * BM + wm * TM + j * 32 + r];
+                if (pass == 0)
+                    mean[j] = s / (float)N;
+                else
+                    rstd[j] = 1.0f / sqrtf(s / (float)N + eps);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = nbase + i * 32 + 8 * gq;
+                const float4 gv = *reinterpret_cast<const float4 *>(gamma + n);
+                const float4 be = *reinterpret_cast<const float4 *>(beta + n);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int64_t m = mbase + j * 32;
+                    const float y0 = (acc[i][j][4 * gq + 0] - mean[j]) * rstd[j] * gv.x + be.x;
+                    const float y1 = (acc[i][j][4 * gq + 1] - mean[j]) * rstd[j] * gv.y + be.y;
+                    const float y2 = (acc[i][j][4 * gq + 2] - mean[j]) * rstd[j] * gv.z + be.z;
+                    const float y3 = (acc[i][j][4 * gq + 3] - mean[j]) * rstd[j] * gv.w + be.w;
+                    uint2 o;
+                    o.x = pack_bf16x2(y0, y1);
+                    o.y = pack_bf16x2(y2, y3);
+                    *reinterpret_cast<uint2 *>(out + m * N + n) = o;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n = nbase + i * 32 + 8 * gq;
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int64_t m = mbase + j * 32;
+                    float y0 = acc[i][j][4 * gq + 0], y1 = acc[i][j][4 * gq + 1];
+                    float y2 = acc[i][j][4 * gq + 2], y3 = acc[i][j][4 * gq + 3];
+                    if constexpr (EPI == EPI_GELU) {
+                        y0 = gelu_erf(y0);
+                        y1 = gelu_erf(y1);
+                        y2 = gelu_erf(y2);
+                        y3 = gelu_erf(y3);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(y0, y1);
+                    o.y = pack_bf16x2(y2, y3);
+                    *reinterpret_cast<uint2 *>(out + m * N + n) = o;
+                }
+            }
+    }
+}
+
+// =====================================================================================================
+// attention on packed tokens.  One workgroup per sequence; work item = (head, query token); keys/values of
+// the sequence stream through LDS in chunks.  fp32 online softmax on the VALU (scores = q.k/sqrt(dh)
+// [+ MPNet relative-position bias]); no mask needed: only valid tokens exist in the packed layout, which
+// equals the reference's additive (1-m)*-10000 mask in fp32 (exp underflows to exactly 0).
+// FLOPs are ~S/(6H) of the layer's (<1 % at the benchmark's 16-token mean length): HBM-bound on qkv.
+// =====================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv,
+                                                        const int32_t *__restrict__ cu, const int32_t *__restrict__ col,
+                                                        const float *__restrict__ relb, int relw, int H,
+                                                        int heads, float scale, int KC, bf16_t *__restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int seq = blockIdx.x;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    if (S <= 0) return;
+    bf16_t *ks = reinterpret_cast<bf16_t *>(smem);       // [KC][H]
+    bf16_t *vs = ks + (size_t)KC * H;                   // [KC][H]
+    int *cs = reinterpret_cast<int *>(vs + (size_t)KC * H);  // [KC] key columns (MPNet bias)
+    const int items = heads * S;
+    const int H3 = 3 * H;
+    for (int w0 = 0; w0 < items; w0 += 256) {
+        const int w = w0 + threadIdx.x;
+        const bool on = w < items;
+        const int head = on ? w / S : 0, qi = on ? w % S : 0;
+        uint32_t q2[DH / 2];
+        {
+            const uint4 *qp = reinterpret_cast<const uint4 *>(qkv + (int64_t)(t0 + qi) * H3 + head * DH);
+#pragma unroll
+            for (int e = 0; e < DH / 8; ++e) {
+                const uint4 v = qp[e];
+                q2[4 * e] = v.x; q2[4 * e + 1] = v.y; q2[4 * e + 2] = v.z; q2[4 * e + 3] = v.w;
+            }
+        }
+        const int qcol = col ? col[t0 + qi] : 0;
+        float mx = -INFINITY, l = 0.f;
+        float acc[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) acc[e] = 0.f;
+        for (int k0 = 0; k0 < S; k0 += KC) {
+            const int kc = (S - k0) < KC ? (S - k0) : KC;
+            __syncthreads();
+            for (int e = threadIdx.x; e < kc * (H / 8); e += 256) {
+                const int j = e / (H / 8), c = e % (H / 8);
+                const uint4 *src = reinterpret_cast<const uint4 *>(qkv + (int64_t)(t0 + k0 + j) * H3 + H) + c;
+                reinterpret_cast<uint4 *>(ks + (size_t)j * H)[c] = src[0];
+                reinterpret_cast<uint4 *>(vs + (size_t)j * H)[c] = src[H / 8];
+            }
+            if (col)
+                for (int j = threadIdx.x; j < kc; j += 256) cs[j] = col[t0 + k0 + j];
+            __syncthreads();
+            if (on) {
+                for (int j = 0; j < kc; ++j) {
+                    const uint4 *kp = reinterpret_cast<const uint4 *>(ks + (size_t)j * H + head * DH);
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < DH / 8; ++e) {
+                        const uint4 kv = kp[e];
+                        const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            s = fmaf(__uint_as_float(q2[4 * e + u] << 16), __uint_as_float(kw[u] << 16), s);
+                            s = fmaf(__uint_as_float(q2[4 * e + u] & 0xffff0000u),
+                                     __uint_as_float(kw[u] & 0xffff0000u), s);
+                        }
+                    }
+                    s *= scale;
+                    if (relb) s += relb[head * relw + (cs[j] - qcol) + (relw >> 1)];
+                    if (s > mx) {
+                        const float corr = __expf(mx - s);
+                        l *= corr;
+#pragma unroll
+                        for (int e = 0; e < DH; ++e) acc[e] *= corr;
+                        mx = s;
+                    }
+                    const float p = __expf(s - mx);
+                    l += p;
+                    const uint4 *vp = reinterpret_cast<const uint4 *>(vs + (size_t)j * H + head * DH);
+#pragma unroll
+                    for (int e = 0; e < DH / 8; ++e) {
+                        const uint4 vv = vp[e];
+                        const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[8 * e + 2 * u] = fmaf(p, __uint_as_float(vw[u] << 16), acc[8 * e + 2 * u]);
+                            acc[8 * e + 2 * u + 1] = fmaf(p, __uint_as_float(vw[u] & 0xffff0000u), acc[8 * e + 2 * u + 1]);
+                        }
+                    }
+                }
+            }
+        }
+        if (on) {
+            const float inv = 1.0f / l;
+            uint4 *op = reinterpret_cast<uint4 *>(ctx + (int64_t)(t0 + qi) * H + head * DH);
+#pragma unroll
+            for (int e = 0; e < DH / 8; ++e) {
+                uint4 o;
+                o.x = pack_bf16x2(acc[8 * e] * inv, acc[8 * e + 1] * inv);
+                o.y = pack_bf16x2(acc[8 * e + 2] * inv, acc[8 * e + 3] * inv);
+                o.z = pack_bf16x2(acc[8 * e + 4] * inv, acc[8 * e + 5] * inv);
+                o.w = pack_bf16x2(acc[8 * e + 6] * inv, acc[8 * e + 7] * inv);
+                op[e] = o;
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// masked mean-pool over the packed layout (A4) + optional fused L2-normalise to bf16 (search operand).
+// One wave per sequence: pooled[b] = sum_t x[t] / max(len, 1e-9).  HBM-bound: T*H*2 B in.
+// =====================================================================================================
+template <int VPL>
+__global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restrict__ x,
+                                                          const int32_t *__restrict__ cu, int B, int H,
+                                                          float *__restrict__ pooled, bf16_t *__restrict__ unit,
+                                                          int ld_unit) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int t0 = cu[b], t1 = cu[b + 1];
+    float s[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s[i] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s[i] += bf16_to_f32(x[(int64_t)t * H + lane + i * 64]);
+    }
+    const float den = fmaxf((float)(t1 - t0), 1e-9f);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        s[i] = s[i] / den;
+        ss = fmaf(s[i], s[i], ss);
+        if (pooled) pooled[(int64_t)b * H + lane + i * 64] = s[i];
+    }
+    if (unit) {
+        const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-8f);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) unit[(int64_t)b * ld_unit + lane + i * 64] = f32_to_bf16(s[i] / nrm);
+        for (int j = H + lane; j < ld_unit; j += 64) unit[(int64_t)b * ld_unit + j] = 0;
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static uint16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace tsim
+
+using namespace tsim;
+
+struct tsim_encoder {
+    tsim_encoder_config cfg;
+    int Tp = 0;
+    // weights
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr, *relb = nullptr;
+    int relw = 0;
+    struct Layer {
+        bf16_t *wqkv, *wo, *w1, *w2;
+        float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+    };
+    std::vector<Layer> layers;
+    std::vector<void *> allocs;
+    // activations
+    bf16_t *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *ctx = nullptr, *h1 = nullptr;
+};
+
+namespace tsim {
+
+static int dev_alloc(tsim_encoder *e, size_t bytes, void **out) {
+    void *p = nullptr;
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) return fail(TSIM_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    e->allocs.push_back(p);
+    *out = p;
+    return TSIM_OK;
+}
+
+static int upload_f32(tsim_encoder *e, const float *h, size_t n, float **out) {
+    int rc = dev_alloc(e, n * 4, (void **)out);
+    if (rc) return rc;
+    TSIM_HIP_CHECK(hipMemcpy(*out, h, n * 4, hipMemcpyHostToDevice));
+    return TSIM_OK;
+}
+
+static int upload_bf16(tsim_encoder *e, const std::vector<const float *> &parts, size_t n_each, bf16_t **out) {
+    std::vector<uint16_t> tmp(n_each * parts.size());
+    for (size_t p = 0; p < parts.size(); ++p)
+        for (size_t i = 0; i < n_each; ++i) tmp[p * n_each + i] = host_f32_to_bf16(parts[p][i]);
+    int rc = dev_alloc(e, tmp.size() * 2, (void **)out);
+    if (rc) return rc;
+    TSIM_HIP_CHECK(hipMemcpy(*out, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    return TSIM_OK;
+}
+
+// MPNet relative_position_bucket (transformers mpnet/modeling_mpnet.py relative_position_bucket):
+// rel = key_col - query_col, n = -rel.
+static int mpnet_bucket(int rel, int num_buckets) {
+    int ret = 0;
+    int n = -rel;
+    const int nb = num_buckets / 2;
+    if (n < 0) {
+        ret += nb;
+        n = -n;
+    }
+    const int max_exact = nb / 2;
+    if (n < max_exact) return ret + n;
+    // float32 arithmetic like torch: log(n / max_exact) / log(128 / max_exact) * (nb - max_exact)
+    const float v = logf((float)n / (float)max_exact) / (float)log(128.0 / max_exact) * (float)(nb - max_exact);
+    int large = max_exact + (int)v;
+    if (large > nb - 1) large = nb - 1;
+    return ret + large;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int EPI>
+static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
+                       const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
+    constexpr int lds = gemm_lds_bytes<BM, BN, BK, WM, WN>();
+    auto kern = gemm_bf16_kernel<BM, BN, BK, WM, WN, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    if (N % BN != 0 || K % BK != 0) return fail(TSIM_EUNSUPPORTED, "gemm: N=%d K=%d not tileable by %dx%d", N, K, BN, BK);
+    const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
+    const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, X, W, bias, res, gamma, beta, eps, out, M, N, K,
+                       mtiles, ntiles);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
+template <int EPI>
+static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, int K,
+                      hipStream_t st) {
+    if (N % 128 == 0)
+        return launch_gemm<128, 128, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
+    return launch_gemm<128, 64, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
+}
+
+static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
+                       const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
+    switch (N) {
+        case 384: return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+        case 768: return launch_gemm<64, 768, 32, 1, 8, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+        case 64: return launch_gemm<128, 64, 64, 4, 2, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+        default: return fail(TSIM_EUNSUPPORTED, "encoder: hidden size %d has no fused LayerNorm GEMM (64, 384, 768)", N);
+    }
+}
+
+}  // namespace tsim
+
+extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_encoder_weights_host *w,
+                                   tsim_encoder **out) {
+    TSIM_REQUIRE(cfg && w && out, "encoder_create: null pointer");
+    const int H = cfg->hidden, F = cfg->ffn, L = cfg->num_layers;
+    TSIM_REQUIRE(H == 64 || H == 384 || H == 768, "encoder_create: hidden=%d unsupported (64, 384, 768)", H);
+    TSIM_REQUIRE(cfg->heads > 0 && H % cfg->heads == 0, "encoder_create: heads=%d does not divide hidden=%d", cfg->heads, H);
+    const int dh = H / cfg->heads;
+    TSIM_REQUIRE(dh == 16 || dh == 32 || dh == 64, "encoder_create: head_dim=%d unsupported (16, 32, 64)", dh);
+    TSIM_REQUIRE(F % 64 == 0 && L > 0 && cfg->max_tokens > 0 && cfg->max_seqs > 0, "encoder_create: bad ffn/layers/capacity");
+    TSIM_REQUIRE(cfg->arch == TSIM_ARCH_BERT || cfg->arch == TSIM_ARCH_MPNET, "encoder_create: unknown arch");
+    TSIM_REQUIRE(w->word_emb && w->pos_emb && w->emb_ln_g && w->emb_ln_b && w->layers, "encoder_create: missing weights");
+    TSIM_REQUIRE(cfg->arch != TSIM_ARCH_MPNET || w->rel_bias, "encoder_create: MPNet needs rel_bias");
+    tsim_encoder *e = new tsim_encoder();
+    e->cfg = *cfg;
+    e->Tp = (cfg->max_tokens + 127) / 128 * 128 + 128;
+    int rc = TSIM_OK;
+    auto bail = [&](int code) {
+        tsim_encoder_destroy(e);
+        return code;
+    };
+    if ((rc = upload_f32(e, w->word_emb, (size_t)cfg->vocab * H, &e->word))) return bail(rc);
+    if ((rc = upload_f32(e, w->pos_emb, (size_t)cfg->max_pos * H, &e->pos))) return bail(rc);
+    if (w->type_emb && (rc = upload_f32(e, w->type_emb, H, &e->type0))) return bail(rc);
+    if ((rc = upload_f32(e, w->emb_ln_g, H, &e->emb_g))) return bail(rc);
+    if ((rc = upload_f32(e, w->emb_ln_b, H, &e->emb_b))) return bail(rc);
+    if (cfg->arch == TSIM_ARCH_MPNET) {
+        const int maxp = cfg->max_pos;
+        e->relw = 2 * maxp - 1;
+        std::vector<float> tab((size_t)cfg->heads * e->relw);
+        for (int d = -(maxp - 1); d <= maxp - 1; ++d) {
+            const int bk = mpnet_bucket(d, cfg->rel_buckets);
+            for (int hh = 0; hh < cfg->heads; ++hh) tab[(size_t)hh * e->relw + d + maxp - 1] = w->rel_bias[bk * cfg->heads + hh];
+        }
+        if ((rc = upload_f32(e, tab.data(), tab.size(), &e->relb))) return bail(rc);
+    }
+    e->layers.resize(L);
+    for (int l = 0; l < L; ++l) {
+        const tsim_layer_weights_host &lw = w->layers[l];
+        tsim_encoder::Layer &d = e->layers[l];
+        if ((rc = upload_bf16(e, {lw.wq, lw.wk, lw.wv}, (size_t)H * H, &d.wqkv))) return bail(rc);
+        if ((rc = upload_bf16(e, {lw.wo}, (size_t)H * H, &d.wo))) return bail(rc);
+        if ((rc = upload_bf16(e, {lw.w1}, (size_t)F * H, &d.w1))) return bail(rc);
+        if ((rc = upload_bf16(e, {lw.w2}, (size_t)H * F, &d.w2))) return bail(rc);
+        std::vector<float> bq(3 * (size_t)H);
+        memcpy(bq.data(), lw.bq, H * 4);
+        memcpy(bq.data() + H, lw.bk, H * 4);
+        memcpy(bq.data() + 2 * H, lw.bv, H * 4);
+        if ((rc = upload_f32(e, bq.data(), bq.size(), &d.bqkv))) return bail(rc);
+        if ((rc = upload_f32(e, lw.bo, H, &d.bo))) return bail(rc);
+        if ((rc = upload_f32(e, lw.b1, F, &d.b1))) return bail(rc);
+        if ((rc = upload_f32(e, lw.b2, H, &d.b2))) return bail(rc);
+        if ((rc = upload_f32(e, lw.ln1_g, H, &d.g1))) return bail(rc);
+        if ((rc = upload_f32(e, lw.ln1_b, H, &d.be1))) return bail(rc);
+        if ((rc = upload_f32(e, lw.ln2_g, H, &d.g2))) return bail(rc);
+        if ((rc = upload_f32(e, lw.ln2_b, H, &d.be2))) return bail(rc);
+    }
+    const size_t Tp = e->Tp;
+    struct { bf16_t **p; size_t n; } acts[] = {{&e->x0, Tp * H}, {&e->x1, Tp * H}, {&e->qkv, Tp * 3 * H},
+                                               {&e->ctx, Tp * H}, {&e->h1, Tp * F}};
+    for (auto &a : acts) {
+        if ((rc = dev_alloc(e, a.n * 2, (void **)a.p))) return bail(rc);
+        if (hipMemset(*a.p, 0, a.n * 2) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail(TSIM_EHIP, "sync after upload failed"));
+    *out = e;
+    return TSIM_OK;
+}
+
+extern "C" void tsim_encoder_destroy(tsim_encoder *e) {
+    if (!e) return;
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, const int32_t *tok_pos,
+                                    const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
+                                    int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit,
+                                    void *last_hidden_bf16, void *stream) {
+    TSIM_REQUIRE(e && tok_ids && tok_pos && cu_seqlens, "encoder_forward: null pointer");
+    TSIM_REQUIRE(T >= 0 && B >= 0 && T <= e->cfg.max_tokens && B <= e->cfg.max_seqs,
+                 "encoder_forward: T=%d B=%d exceed capacity (%d tokens, %d sequences)", T, B, e->cfg.max_tokens, e->cfg.max_seqs);
+    TSIM_REQUIRE(max_len <= e->cfg.max_pos, "encoder_forward: max_len=%d > max_pos=%d", max_len, e->cfg.max_pos);
+    TSIM_REQUIRE(!unit_bf16 || ld_unit >= e->cfg.hidden, "encoder_forward: ld_unit < hidden");
+    if (B == 0) return TSIM_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const tsim_encoder_config &c = e->cfg;
+    const int H = c.hidden, F = c.ffn, dh = H / c.heads;
+    int rc;
+    if (T > 0) {
+        const unsigned g = (unsigned)((T + 3) / 4);
+#define EMBED(V) hipLaunchKernelGGL(embed_ln_kernel<V>, dim3(g), dim3(256), 0, st, tok_ids, tok_pos, e->word, e->pos, e->type0, e->emb_g, e->emb_b, c.ln_eps, T, H, e->x0)
+        if (H == 64) EMBED(1); else if (H == 384) EMBED(6); else EMBED(12);
+#undef EMBED
+        TSIM_HIP_CHECK(hipGetLastError());
+        const int KC = H <= 384 ? 32 : 16;
+        const size_t att_lds = (size_t)KC * H * 2 * 2 + KC * 4;
+        const float scale = 1.0f / sqrtf((float)dh);
+        const int32_t *col = c.arch == TSIM_ARCH_MPNET ? (tok_col ? tok_col : tok_pos) : nullptr;
+        for (int l = 0; l < c.num_layers; ++l) {
+            const tsim_encoder::Layer &L = e->layers[l];
+            if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
+#define ATT(D) hipLaunchKernelGGL(attention_kernel<D>, dim3(B), dim3(256), att_lds, st, e->qkv, cu_seqlens, col, e->relb, e->relw, H, c.heads, scale, KC, e->ctx)
+            if (dh == 16) ATT(16); else if (dh == 32) ATT(32); else ATT(64);
+#undef ATT
+            TSIM_HIP_CHECK(hipGetLastError());
+            if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, st))) return rc;
+            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.b1, e->h1, T, F, H, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, st))) return rc;
+        }
+        if (last_hidden_bf16)
+            TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));
+    }
+    if (pooled_f32 || unit_bf16) {
+        const unsigned g = (unsigned)((B + 3) / 4);
+#define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (bf16_t *)unit_bf16, ld_unit)
+        if (H == 64) POOL(1); else if (H == 384) POOL(6); else POOL(12);
+#undef POOL
+        TSIM_HIP_CHECK(hipGetLastError());
+    }
+    return TSIM_OK;
+}

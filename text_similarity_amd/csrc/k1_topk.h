@@ -1,0 +1,295 @@
+// K1 of the cosine top-k path: fused MFMA scoring + per-lane top-k selection (gfx950).
+// Included by k1_kl16.hip / k1_kl32.hip (one translation unit per list length so they build in parallel).
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+namespace tsim {
+
+// =====================================================================================================
+// K1: cos_topk_partial — the hot kernel.
+//
+// Work decomposition: workgroup = (query block of NWAVES*32 queries) x (corpus chunk of rows_per_chunk
+// rows).  Each wave keeps its 32 query rows resident in VGPRs as the MFMA B operand (D/16 k-steps x 4
+// VGPRs = 96 VGPRs at D = 384), so the only operand that moves in the main loop is the corpus.  Corpus
+// tiles of 32 rows stream HBM -> LDS with LDS-DMA (global_load_lds_dwordx4, a 3-stage ring, counted vmcnt,
+// one raw s_barrier per tile) and are shared by all waves of the workgroup.  Per tile and wave: D/16
+// v_mfma_f32_32x32x16_bf16 with A = corpus tile (ds_read_b128 from an XOR-swizzled row-major image), the
+// 32x32 score tile stays in 16 accumulator VGPRs: lane (r, h) holds query r against corpus rows
+// {(reg&3) + 8*(reg>>2) + 4*h}.  Because the query sits on the lane, top-k selection needs no cross-lane
+// traffic: one threshold VGPR (the lane's current KL-th best), a max3 tree over the 16 accumulators and a
+// wave-uniform branch reject almost every tile; survivors are appended to a per-lane queue in LDS and
+// drained in bulk (all 64 lanes insert into their sorted register lists together), which amortises the
+// insertion network over up to 64 candidates.
+//
+// Output: per (query, chunk, lane-half) a sorted list of KL (score, local row) pairs; K2 merges them.
+// Roofline: 2*32*32*D FLOP per tile and wave on the MFMA pipe; D*2 bytes per corpus row from HBM once
+// per query block; nothing proportional to Q*N is ever written.
+// =====================================================================================================
+constexpr int K1_TILE_ROWS = 32;
+constexpr int K1_NSTAGE = 3;
+constexpr int K1_QCAP = 8;  // per-lane candidate queue depth (entries)
+
+template <int KL>
+__device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], float s, int i) {
+    // bubble (s,i) down a list sorted by score descending.  Strict '>' keeps the element that was seen
+    // earlier ahead of a later one with an equal score; a lane sees corpus rows in increasing order, so
+    // ties resolve to the lower index.  s = -inf is a no-op.
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        const bool gt = s > ls[j];
+        const float ns = gt ? ls[j] : s;
+        const int ni = gt ? li[j] : i;
+        ls[j] = gt ? s : ls[j];
+        li[j] = gt ? i : li[j];
+        s = ns;
+        i = ni;
+    }
+}
+
+template <int D, int NWAVES>
+constexpr int k1_lds_bytes() {
+    return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * K1_QCAP * 64 * 8;
+}
+
+template <int D, int NWAVES, int KL>
+__global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
+    const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
+    int nchunks, int nqb, const float *__restrict__ thr_in, float *__restrict__ part_s,
+    int *__restrict__ part_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = D * 2;                        // bytes per corpus row
+    constexpr int STAGE_BYTES = K1_TILE_ROWS * ROWB;   // 24 KiB at D = 384
+    constexpr int KSTEPS = D / 16;
+    constexpr int CH16 = D / 8;                        // 16-byte chunks per row
+    constexpr int PIECES = STAGE_BYTES / 1024;         // 1-KiB LDS-DMA wave-instructions per stage
+    static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
+    constexpr int PPW = PIECES / NWAVES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5, x = r & 15;
+
+    // blockIdx -> (query block, corpus chunk).  Blocks b and b+8 share an XCD (round-robin dispatch), so
+    // the nqb query blocks of one chunk are given the same b%8: they stream the same corpus rows at about
+    // the same time and share them through that XCD's L2.  Speed only; any placement is correct.
+    const int b = blockIdx.x;
+    const int xcd = b & 7, jj = b >> 3;
+    const int qb = jj % nqb;
+    const int chunk = (jj / nqb) * 8 + xcd;
+    if (chunk >= nchunks) return;
+
+    const int64_t row0 = (int64_t)chunk * rows_per_chunk;
+    const int crows = (int)(((N - row0) < (int64_t)rows_per_chunk) ? (N - row0) : (int64_t)rows_per_chunk);
+    const int ntiles = (crows + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
+    const int q0 = qb * (NWAVES * 32) + wave * 32;
+    const bool wave_on = q0 < Q;  // wave-uniform: waves past the last query only help staging
+    const int qrow = (q0 + r < Q) ? (q0 + r) : (Q - 1);
+
+    // ---- resident query fragments: B[k = 8h + j][col r] of k-step s = eq[q0 + r][16 s + 8 h + j]
+    bf16x8 bq[KSTEPS];
+    {
+        const bf16_t *qp = eq + (int64_t)qrow * D + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) bq[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+    }
+    float thr = thr_in ? thr_in[qrow] : -INFINITY;
+    // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
+    // and is waited for with counted vmcnt (cdna_hip_programming.md §5, "Three .s-level traps" (b)).
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bq[s]));
+    asm volatile("" : "+v"(thr));
+
+    // ---- LDS-DMA source offsets.  LDS image of a stage = the 32 rows back to back (row-major, 16-byte
+    // slots), slot c of row rr holding source chunk c ^ (rr & 15): the XOR makes the ds_read_b128 of the
+    // A fragment (32 lanes = 32 rows, same chunk) conflict-free while every 256-byte source segment is
+    // still read whole.  LDS-DMA writes lane-linearly, so the permutation goes on the SOURCE address.
+    int src_row[PPW], src_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int slot = (wave * PPW + i) * 64 + lane;
+        const int rr = slot / CH16, cc = slot % CH16;
+        src_row[i] = rr;
+        src_off[i] = (cc ^ (rr & 15)) * 16;
+    }
+    auto issue_tile = [&](int t, int stage) {
+        const int tt = t < ntiles ? t : ntiles - 1;  // past-the-end tiles re-read the last one: keeps vmcnt uniform
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int64_t gr = row0 + (int64_t)tt * K1_TILE_ROWS + src_row[i];
+            gr = gr < N ? gr : N - 1;
+            const char *src = reinterpret_cast<const char *>(ec) + gr * ROWB + src_off[i];
+            glds16(src, smem + stage * STAGE_BYTES + (wave * PPW + i) * 1024);
+        }
+    };
+
+    // A-fragment read offsets: lane (r,h), k-step s reads chunk (2s+h) of row r -> slot (2s+h) ^ x.
+    // (2s+h) ^ x = 16*(s>>3) + ((2*(s&7)+h) ^ x): eight base offsets + an immediate.
+    int aoff[8];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) aoff[bb] = r * ROWB + (((2 * bb + h) ^ x) << 4);
+
+    float ls[KL];
+    int li[KL];
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        ls[j] = -INFINITY;
+        li[j] = -1;
+    }
+    int cnt = 0;
+    // Per-lane candidate queue in LDS: entry p of this lane at qaddr + p*512 (lanes interleaved, 8 B each).
+    // Accessed with inline asm: hipcc would otherwise drain the LDS-DMA ring (s_waitcnt vmcnt(0)) before
+    // every ordinary LDS access that might alias it; the queue never overlaps the staging buffers.
+    const uint32_t qaddr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) +
+                           K1_NSTAGE * STAGE_BYTES + wave * (K1_QCAP * 64 * 8) + lane * 8;
+
+    auto drain = [&]() {
+#pragma unroll 1
+        for (int p = 0; p < K1_QCAP; ++p) {
+            if (!__any(p < cnt)) break;
+            uint64_t e;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(qaddr + p * 512) : "memory");
+            const float s = (p < cnt) ? __uint_as_float((uint32_t)e) : -INFINITY;
+            list_insert<KL>(ls, li, s, (int)(e >> 32));
+        }
+        cnt = 0;
+        thr = fmaxf(thr, ls[KL - 1]);
+    };
+
+    issue_tile(0, 0);
+    issue_tile(1, 1);
+
+    auto do_tile = [&](int t, int stage) {
+        wait_vmcnt<PPW>();                 // my pieces of tile t have landed (tile t+1 may be in flight)
+        __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading tile t-1
+        issue_tile(t + 2, (stage + 2) % K1_NSTAGE);
+        if (!wave_on) return;
+        const char *abase = smem + stage * STAGE_BYTES;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[s], acc, 0, 0, 0);
+        }
+        const int trow = t * K1_TILE_ROWS + 4 * h;  // local (chunk-relative) row of acc[0]
+        if ((t + 1) * K1_TILE_ROWS > crows) {       // ragged last tile: rows past the chunk never compete
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (trow + (g & 3) + 8 * (g >> 2) >= crows) acc[g] = -INFINITY;
+        }
+        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int g = 3; g < 15; g += 2) m = fmaxf(fmaxf(m, acc[g]), acc[g + 1]);
+        m = fmaxf(m, acc[15]);
+        if (__any(m > thr)) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const bool p = acc[g] > thr;
+                if (__any(p)) {
+                    if (p) {
+                        const uint64_t e = (uint64_t)__float_as_uint(acc[g]) |
+                                           ((uint64_t)(uint32_t)(trow + (g & 3) + 8 * (g >> 2)) << 32);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(qaddr + cnt * 512), "v"(e) : "memory");
+                        cnt++;
+                    }
+                    if (__any(cnt == K1_QCAP)) drain();
+                }
+            }
+        }
+    };
+
+    int t = 0;
+    for (; t + 3 <= ntiles; t += 3) {
+        do_tile(t, 0);
+        do_tile(t + 1, 1);
+        do_tile(t + 2, 2);
+    }
+    if (t < ntiles) do_tile(t, 0);
+    if (t + 1 < ntiles) do_tile(t + 1, 1);
+    wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
+
+    if (wave_on) {
+        drain();
+        if (q0 + r < Q) {
+            const int P2 = nchunks * 2;
+            const int64_t o = ((int64_t)(q0 + r) * P2 + chunk * 2 + h) * KL;
+            const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
+#pragma unroll
+            for (int j = 0; j < KL; j += 4) {
+                *reinterpret_cast<float4 *>(part_s + o + j) = make_float4(ls[j], ls[j + 1], ls[j + 2], ls[j + 3]);
+                int4 iv;
+                iv.x = li[j] < 0 ? -1 : li[j] + base;
+                iv.y = li[j + 1] < 0 ? -1 : li[j + 1] + base;
+                iv.z = li[j + 2] < 0 ? -1 : li[j + 2] + base;
+                iv.w = li[j + 3] < 0 ? -1 : li[j + 3] + base;
+                *reinterpret_cast<int4 *>(part_i + o + j) = iv;
+            }
+        }
+    }
+}
+
+struct TopkPlan {
+    int nqb, nchunks, rows_per_chunk, P2, KL, nwaves;
+    size_t part_elems;
+};
+
+static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
+    p->KL = k <= 12 ? 16 : 32;
+    p->nwaves = D <= 384 ? 8 : 4;
+    const int qpb = p->nwaves * 32;
+    p->nqb = (int)((Q + qpb - 1) / qpb);
+    // enough workgroups to fill 256 CUs a few times over, but chunks as long as possible: the per-lane
+    // selection cost falls with stream length (candidates ~ KL*ln(n/KL))
+    int64_t target = 512;
+    int64_t nch = (target + p->nqb - 1) / p->nqb;
+    int64_t max_ch = (N + 255) / 256;  // at least 256 rows per chunk
+    if (nch > max_ch) nch = max_ch;
+    if (nch < 1) nch = 1;
+    int64_t rpc = (N + nch - 1) / nch;
+    rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;
+    p->rows_per_chunk = (int)rpc;
+    p->nchunks = (int)((N + rpc - 1) / rpc);
+    p->P2 = p->nchunks * 2;
+    p->part_elems = (size_t)Q * p->P2 * p->KL;
+    return 0;
+}
+
+template <int D, int NWAVES, int KL>
+static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+                     float *part_s, int *part_i, hipStream_t st) {
+    constexpr int lds = k1_lds_bytes<D, NWAVES>();
+    auto kern = cos_topk_partial_kernel<D, NWAVES, KL>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    const int grid = ((p.nchunks + 7) / 8) * 8 * p.nqb;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, eq, (int)Q, ec, N, p.rows_per_chunk,
+                       p.nchunks, p.nqb, (const float *)nullptr, part_s, part_i);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
+template <int KL>
+static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+                        float *part_s, int *part_i, hipStream_t st) {
+    switch (D) {
+        case 128: return launch_k1<128, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 256: return launch_k1<256, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 384: return launch_k1<384, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 512: return launch_k1<512, 4, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 768: return launch_k1<768, 4, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
+    }
+}
+
+
+int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+                   float *part_s, int *part_i, hipStream_t st);
+int k1_launch_kl32(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+                   float *part_s, int *part_i, hipStream_t st);
+
+}  // namespace tsim

@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the embed-and-search hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): "sentences/sec encoded + Mpairs/sec cosine top-k @ N=1M d=384".
+
+Workload (config.workload): all-MiniLM-L6-v2 architecture preset (synthetic weights), a corpus of 1 M x 384
+L2-normalised bf16 rows RESIDENT IN HBM PER GPU (SURVEY.md §8(d) synthetic embeddings), and per step one batch of
+Q synthetic sentences (pre-tokenised, resident in HBM) that is encoded (bf16 MFMA encoder -> masked mean-pool ->
+unit bf16 rows) and searched against the corpus (fused MFMA cosine + top-10, exact (score desc, index asc) order).
+One step = one pass of the whole hot path over one query batch.  With N GPUs the corpus is sharded (1 M rows per GPU,
+weak scaling of the pair count), each rank encodes Q/N of the batch, query rows are all-gathered over RCCL, every rank
+searches all Q queries against its shard and the per-shard top-10 lists are all-gathered and merged.
+
+`value` = scored (query, corpus-row) pairs per second over the whole job, in Mpairs/s, from the wall time of the K
+timed steps (encode INCLUDED).  `sentences_per_s` is the same time base.  Per-phase rates from HIP events are reported
+under `phases`.  `roofline` is for the dominant kernel, cos_topk_partial: algorithmic FLOPs 2*Q*N_local*d per launch
+(768 FLOP/pair) over its HIP-event duration on its own stream, against the dense bf16 MFMA peak; the HBM streaming
+figure (ceil(Q/256) * N * d * 2 B per launch) is reported beside it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, Chip-level parameters)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def cpu_baseline(preset: str, d: int, n_rows: int, k: int):
+    """The oracle (CPU port of the reference path) on this box's host cores, bounded to ~10-30 s."""
+    from oracle import encoder_ref
+    from text_similarity_amd import presets
+    # the box gives one GPU job a 16-core share; os.cpu_count() reports the whole host and oversubscribes torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
+    torch.set_num_threads(threads)
+    cfg = presets.PRESETS[preset]
+    w = presets.synthetic_weights(preset)
+    wt = {kk: torch.from_numpy(v) for kk, v in w.items()}
+    n_sent = 128
+    flat, cu = presets.synthetic_token_batch(n_sent, seed="sent1234", vocab_size=cfg.vocab, max_len=256)
+    t0 = time.perf_counter()
+    encoder_ref.encode_packed(cfg, wt, flat, cu, batch_size=16)
+    t_enc = time.perf_counter() - t0
+    # search: the reference loop is expand + cosine_similarity + topk per query on fp32; timed here in its
+    # fastest CPU form (one fp32 GEMM over unit rows + topk), which favours the CPU
+    g = torch.Generator().manual_seed(4321)
+    corpus = torch.nn.functional.normalize(torch.randn((n_rows, d), generator=g), dim=1)
+    qn = 64
+    q = torch.nn.functional.normalize(torch.randn((qn, d), generator=g), dim=1)
+    (q[:8] @ corpus.T).topk(k, dim=1)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 6.0 and reps < 50:
+        (q @ corpus.T).topk(k, dim=1)
+        reps += 1
+    t_s = (time.perf_counter() - t0) / reps
+    return {"value": round(qn * n_rows / t_s / 1e6, 1), "unit": "Mpairs/s", "cores": threads, "kind": "port",
+            "sample": f"oracle on host: cosine top-{k} of {qn} queries x {n_rows} rows x d={d} fp32 (torch.mm+topk, "
+                      f"{reps} reps, {t_s * 1e3:.0f} ms each); encode {n_sent} synthetic sentences fp32 in {t_enc:.1f} s",
+            "encode_sentences_per_s": round(n_sent / t_enc, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=4096, help="sentences per step over the whole job")
+    ap.add_argument("--corpus-rows", type=int, default=1_000_000, help="corpus rows per GPU")
+    ap.add_argument("--preset", default="all-MiniLM-L6-v2")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from text_similarity_amd import _lib, ops, presets
+    from text_similarity_amd.distributed.sharded_search import ShardedCorpusSearch
+    from text_similarity_amd.native_encoder import NativeEncoder
+
+    cfg = presets.PRESETS[args.preset]
+    d, k = cfg.hidden, args.k
+    Q = args.queries - args.queries % world
+    q_local = Q // world
+    n_local = args.corpus_rows
+
+    # ---- resident inputs (untimed): corpus shard, query-sentence batches, encoder weights
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    corpus = ops.l2norm_rows(torch.randn((n_local, d), generator=g, device=dev))
+    nb = 8  # distinct query batches, cycled
+    flat_h, cu_h = presets.synthetic_token_batch(Q * nb, seed="sent1234", vocab_size=cfg.vocab, max_len=256)
+    batches = []
+    for b in range(nb):
+        lo = b * Q + rank * q_local
+        t0, t1 = int(cu_h[lo]), int(cu_h[lo + q_local])
+        batches.append((torch.from_numpy(flat_h[t0:t1]).to(dev),
+                        torch.from_numpy((cu_h[lo:lo + q_local + 1] - cu_h[lo]).astype(np.int32)).to(dev)))
+    max_tok = max(int(b[0].numel()) for b in batches)
+    enc = NativeEncoder.from_preset(args.preset, max_tokens=max_tok, max_seqs=q_local, device=dev)
+    pos = [enc.positions(f, c) for f, c in batches]
+    max_len = [int((c[1:] - c[:-1]).max().item()) for _, c in batches]
+    engine = ShardedCorpusSearch(corpus, d, rank * n_local)
+    mean_tokens = float(cu_h[-1]) / (Q * nb)
+
+    L = _lib.lib()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i, rec=None):
+        f, c = batches[i % nb]
+        p, cols = pos[i % nb]
+        if rec is not None:
+            rec["e0"].record(stream)
+        unit = enc.forward_packed(f, c, p, cols, max_len[i % nb], pooled=True, unit=True)["unit"]
+        if rec is not None:
+            rec["e1"].record(stream)
+            L.tsim_time_next_topk(rec["k0"].cuda_event, rec["k1"].cuda_event)
+        s, idx = engine.search(unit, k)
+        if rec is not None:
+            rec["e2"].record(stream)
+        return s, idx
+
+    for i in range(args.warmup):
+        step(i)
+    recs = [{n: ev() for n in ("e0", "e1", "e2", "k0", "k1")} for _ in range(args.steps)]
+    for r in recs:      # hipEventCreate happens lazily at first record: do it outside the timed region
+        for e in r.values():
+            e.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i, recs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity of the last result (not timed): sorted lists, indices inside the global corpus
+    s_last, i_last = out
+    assert s_last.shape == (Q, k) and bool((s_last[:, :-1] >= s_last[:, 1:]).all())
+    assert int(i_last.min()) >= 0 and int(i_last.max()) < n_local * world
+
+    enc_ms = float(np.mean([r["e0"].elapsed_time(r["e1"]) for r in recs]))
+    srch_ms = float(np.mean([r["e1"].elapsed_time(r["e2"]) for r in recs]))
+    k1_ms = float(np.mean([r["k0"].elapsed_time(r["k1"]) for r in recs]))
+    if rank == 0:
+        pairs = float(Q) * n_local * world * args.steps
+        k1_flops = 2.0 * Q * n_local * d                      # per launch (this rank's shard)
+        k1_stream_bytes = -(-Q // 256) * n_local * d * 2.0      # corpus streamed once per 256-query block
+        H, F, Ly = cfg.hidden, cfg.ffn, cfg.num_layers
+        lens = np.diff(cu_h).astype(np.float64)
+        sbar = float((lens ** 2).sum() / lens.sum())
+        enc_flops = q_local * mean_tokens * Ly * (2 * (4 * H * H + 2 * H * F) + 4 * sbar * H)
+        res = {
+            "metric": "sentences/sec encoded + Mpairs/sec cosine top-k @ N=1M d=384",
+            "value": round(pairs / elapsed / 1e6, 1), "unit": "Mpairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.preset} preset (synthetic weights): encode {Q} synthetic sentences/step "
+                                   f"(mean {mean_tokens:.1f} tokens) + cosine top-{k} vs {n_local} x {d} bf16 corpus rows per GPU "
+                                   f"resident in HBM (BASELINE configs[1] path at the metric's N=1M, d=384)",
+                       "queries_per_step": Q, "corpus_rows_per_gpu": n_local, "d": d, "k": k,
+                       "parallelism": f"corpus-sharded x{world}, queries all-gathered (RCCL)" if world > 1 else "single GPU"},
+            "sentences_per_s": round(Q * args.steps / elapsed, 1),
+            "phases": {"encode_ms": round(enc_ms, 4), "search_ms": round(srch_ms, 4),
+                       "encode_sentences_per_s_per_gpu": round(q_local / enc_ms * 1e3, 1),
+                       "encode_tflops_per_gpu": round(enc_flops / enc_ms / 1e9, 1),
+                       "search_mpairs_per_s_per_gpu": round(Q * n_local / srch_ms / 1e3, 1)},
+            "roofline": {"bound": "mfma", "kernel": "cos_topk_partial_kernel<384,8,16>",
+                         "achieved": round(k1_flops / k1_ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(k1_flops / k1_ms / 1e9 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(k1_ms, 4), "flops_per_launch": k1_flops,
+                         "hbm_stream_GBs": round(k1_stream_bytes / k1_ms / 1e6, 1),
+                         "hbm_stream_frac": round(k1_stream_bytes / k1_ms / 1e6 / PEAK_HBM_GBS, 4), "query_block": 256},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.preset, d, n_local, k)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

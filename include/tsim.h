@@ -68,6 +68,11 @@ int tsim_cosine_topk(const void *eq_bf16, int64_t Q, const void *ec_bf16, int64_
                      int k, float *out_scores, int64_t *out_idx, int64_t idx_offset,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Measurement hook (bench.py): the NEXT tsim_cosine_topk call of the calling thread records `start` right before
+ * and `stop` right after the launch of its dominant kernel (cos_topk_partial) on the call's stream.  Both are
+ * hipEvent_t handles passed as void*; the hook is cleared by that call.  Pass NULLs to cancel. */
+void tsim_time_next_topk(void *start_event, void *stop_event);
+
 /* Merge `nlists` sorted candidate lists per query (the per-shard results of tsim_cosine_topk on the
  * shards of a partitioned corpus, or the per-chunk results of search_pipeline.py:60 `corpus_chunk_size`
  * chunking): scores/idx are [nlists, Q, k_in]; output [Q, k_out] by (score desc, index asc);

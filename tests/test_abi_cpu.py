@@ -1,0 +1,104 @@
+"""CPU checks of the boundary: libtsim.so loads, exports every symbol include/tsim.h declares, rejects bad arguments
+with the documented error codes (no kernel is launched), and the product refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from text_similarity_amd import _lib, ops
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from text_similarity_amd.build import build
+        build(verbose=False)
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    hdr = open(os.path.join(REPO, "include", "tsim.h")).read()
+    declared = set(re.findall(r"\b(tsim_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tsim_pad_dim"} - {"tsim_pad_dim"}  # keep all
+    cdll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(cdll, name), f"{name} declared in include/tsim.h but not exported"
+    assert declared == set(_lib.DECLARED_SYMBOLS), declared ^ set(_lib.DECLARED_SYMBOLS)
+
+
+def test_pure_host_entry_points(lib):
+    assert lib.tsim_version() >= 100
+    assert [lib.tsim_pad_dim(d) for d in (1, 64, 128, 129, 384, 385, 768, 769)] == [128, 128, 128, 256, 384, 512, 768, 0]
+    assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 10) > 0
+    assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 29) == 0
+    with pytest.raises(ValueError):
+        ops.pad_dim(1000)
+
+
+def test_argument_validation_returns_error_codes(lib):
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    # k out of range, empty corpus, wrong row stride, null pointers: all rejected before any launch
+    assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 0, p, p, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 40, p, p, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk(p, 4, p, 0, 384, 384, 10, p, p, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 400, 10, p, p, 0, p, 4096, None) == 1
+    assert b"tsim_pad_dim" in lib.tsim_last_error()
+    assert lib.tsim_cosine_topk(None, 4, p, 100, 384, 384, 10, p, p, 0, p, 4096, None) == 1
+    assert lib.tsim_l2norm_rows(p, 7, 4, 384, 384, p, 384, 1e-8, None) == 1
+    assert lib.tsim_mean_pool(None, 0, p, 1, 1, 1, p, None) == 1
+    with pytest.raises(ValueError):
+        _lib.check(1, "x")
+
+
+def test_product_has_no_cpu_path():
+    x = torch.zeros(4, 384)
+    for call in (lambda: ops.l2norm_rows(x), lambda: ops.cos_sim_dense(x, x),
+                 lambda: ops.cosine_topk(x.bfloat16(), x.bfloat16(), 384, 2),
+                 lambda: ops.mean_pool(torch.zeros(1, 2, 3), torch.ones(1, 2))):
+        with pytest.raises(_lib.TsimError):
+            call()
+    if not torch.cuda.is_available():
+        from text_similarity_amd.native_encoder import NativeEncoder
+        with pytest.raises(_lib.TsimError):
+            NativeEncoder.from_preset("tiny-bert")
+
+
+def test_reference_named_api_imports_and_containers():
+    from text_similarity_amd.configurations.config import Configuration, ModelParameters, SearchConfiguration
+    from text_similarity_amd.dataset.dataset import EmbeddingsFeatures
+    from text_similarity_amd.models.sentence_encoder import OnnxSentenceTransformerWrapper, SentenceTransformerWrapper  # noqa
+    from text_similarity_amd.modules.modules import AvgPoolingStrategy  # noqa
+    from text_similarity_amd.pipeline.search_pipeline import Pipeline, SearchPipeline, SentenceMiningPipeline
+    from text_similarity_amd.utils.metrics import cos_sim  # noqa
+    c = Configuration(ModelParameters("m"), "m", "/tmp")
+    assert (c.sequence_max_len, c.batch_size) == (256, 16)           # config.py:29,32
+    s = SearchConfiguration(ModelParameters("m"), "m", "/tmp")
+    assert (s.ef, s.ef_construction, s.M) == (50, 400, 64)
+    f = EmbeddingsFeatures(torch.ones(1, 2), torch.ones(1, 2))
+    assert set(f.to_dict()) == {"input_ids", "attention_mask"}         # dataset.py:230-240
+    assert set(EmbeddingsFeatures.from_dict({**f.to_dict(), "token_type_ids": torch.zeros(1, 2)}).to_dict()) == \
+        {"input_ids", "attention_mask", "token_type_ids"}
+    p = SentenceMiningPipeline(100, c, model=None, corpus=["a", "b"])
+    assert isinstance(p, SearchPipeline) and isinstance(p, Pipeline) and p.corpus_chunk_size == 100
+    t = torch.zeros(2, 3)
+    assert p.encode_corpus(t) is t                                    # tensors pass through (search_pipeline.py:19-22)
+
+
+def test_synthetic_generators_are_deterministic():
+    from text_similarity_amd import presets
+    a = presets.uniform01("s", 5)
+    np.testing.assert_array_equal(a, presets.uniform01("s", 10)[:5])
+    np.testing.assert_array_equal(presets.uniform01("s", 5, offset=5), presets.uniform01("s", 10)[5:])
+    x = presets.normal("n", 1000)
+    assert abs(float(x.mean())) < 0.15 and 0.85 < float(x.std()) < 1.15
+    e = presets.synthetic_embeddings(4, 384, "e")
+    np.testing.assert_array_equal(e, presets.bf16_round(e))
+    assert presets.to_bf16_bits(np.array([1.0, -2.0], np.float32)).tolist() == [0x3F80, 0xC000]
+    w = presets.synthetic_weights("tiny-mpnet")
+    assert "encoder.relative_attention_bias.weight" in w and "embeddings.token_type_embeddings.weight" not in w

@@ -48,6 +48,7 @@ _SIGS = {
     "tsim_cosine_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "tsim_cosine_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "tsim_time_next_topk": (None, [C.c_void_p, C.c_void_p]),
     "tsim_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "tsim_cos_sim": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

@@ -296,109 +296,135 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
 }
 
 // =====================================================================================================
-// attention on packed tokens.  One workgroup per sequence; work item = (head, query token); keys/values of
-// the sequence stream through LDS in chunks.  fp32 online softmax on the VALU (scores = q.k/sqrt(dh)
-// [+ MPNet relative-position bias]); no mask needed: only valid tokens exist in the packed layout, which
-// equals the reference's additive (1-m)*-10000 mask in fp32 (exp underflows to exactly 0).
-// FLOPs are ~S/(6H) of the layer's (<1 % at the benchmark's 16-token mean length): HBM-bound on qkv.
+// attention on packed tokens (MFMA).  One wave per (sequence, head, block of 32 queries); a workgroup = 4 heads.
+//   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q rows: the QUERY lands on the lane (column), 16 keys
+//                 in the accumulator registers -> softmax statistics are lane-local plus one cross-half shuffle;
+//   O^T = V^T P^T the score accumulator, converted pairwise to bf16, IS the B operand of the second product
+//                 (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand"); the k order inside a
+//                 k-step is then key = 16s + 8(j>>2) + 4h + (j&3), and the V^T fragment is gathered in that order.
+// fp32 online softmax over key blocks of 32 (scores = q.k/sqrt(dh) [+ MPNet relative-position bias]).  No mask is
+// needed: the packed layout holds valid tokens only, which equals the reference's additive (1-m)*-10000 mask in fp32
+// (exp underflows to exactly 0).  Operands come straight from HBM/L2 (each byte of qkv is read once per query block);
+// FLOPs are ~S/(6H) of the layer's (<1 % at the benchmark's 16-token mean length): HBM/latency-bound.
 // =====================================================================================================
-template <int DH>
+template <int DH, bool REL>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv,
                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ col,
                                                         const float *__restrict__ relb, int relw, int H,
-                                                        int heads, float scale, int KC, bf16_t *__restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int seq = blockIdx.x;
+                                                        int heads, float scale, bf16_t *__restrict__ ctx) {
+    constexpr int KS = DH / 16;            // k-steps of the QK^T product
+    constexpr int OT = (DH + 31) / 32;     // 32-row blocks of O^T
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seq = blockIdx.x, head = blockIdx.y * 4 + wave, qb = blockIdx.z;
     const int t0 = cu[seq], S = cu[seq + 1] - t0;
-    if (S <= 0) return;
-    bf16_t *ks = reinterpret_cast<bf16_t *>(smem);       // [KC][H]
-    bf16_t *vs = ks + (size_t)KC * H;                   // [KC][H]
-    int *cs = reinterpret_cast<int *>(vs + (size_t)KC * H);  // [KC] key columns (MPNet bias)
-    const int items = heads * S;
-    const int H3 = 3 * H;
-    for (int w0 = 0; w0 < items; w0 += 256) {
-        const int w = w0 + threadIdx.x;
-        const bool on = w < items;
-        const int head = on ? w / S : 0, qi = on ? w % S : 0;
-        uint32_t q2[DH / 2];
-        {
-            const uint4 *qp = reinterpret_cast<const uint4 *>(qkv + (int64_t)(t0 + qi) * H3 + head * DH);
+    if (qb * 32 >= S || head >= heads) return;  // wave-uniform
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t H3 = 3 * (int64_t)H;
+    const int qi = qb * 32 + r;
+    const int tq = t0 + (qi < S ? qi : S - 1);
+
+    bf16x8 qf[KS];
+    {
+        const bf16_t *qp = qkv + tq * H3 + head * DH + 8 * h;
 #pragma unroll
-            for (int e = 0; e < DH / 8; ++e) {
-                const uint4 v = qp[e];
-                q2[4 * e] = v.x; q2[4 * e + 1] = v.y; q2[4 * e + 2] = v.z; q2[4 * e + 3] = v.w;
+        for (int s = 0; s < KS; ++s) {
+            qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        }
+    }
+    const int qcol = REL ? col[tq] : 0;
+    f32x16 o[OT];
+#pragma unroll
+    for (int ob = 0; ob < OT; ++ob)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[ob][g] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int kr = k0 + r;
+        const int tk = t0 + (kr < S ? kr : S - 1);
+        f32x16 sc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sc[g] = 0.f;
+        {
+            const bf16_t *kp = qkv + tk * H3 + H + head * DH + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + 16 * s);
+                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
             }
         }
-        const int qcol = col ? col[t0 + qi] : 0;
-        float mx = -INFINITY, l = 0.f;
-        float acc[DH];
+        // sc[g]: key k0 + (g&3) + 8(g>>2) + 4h, query qi
+        float bm = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < DH; ++e) acc[e] = 0.f;
-        for (int k0 = 0; k0 < S; k0 += KC) {
-            const int kc = (S - k0) < KC ? (S - k0) : KC;
-            __syncthreads();
-            for (int e = threadIdx.x; e < kc * (H / 8); e += 256) {
-                const int j = e / (H / 8), c = e % (H / 8);
-                const uint4 *src = reinterpret_cast<const uint4 *>(qkv + (int64_t)(t0 + k0 + j) * H3 + H) + c;
-                reinterpret_cast<uint4 *>(ks + (size_t)j * H)[c] = src[0];
-                reinterpret_cast<uint4 *>(vs + (size_t)j * H)[c] = src[H / 8];
+        for (int g = 0; g < 16; ++g) {
+            const int key = k0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            float v = sc[g] * scale;
+            if (REL) {
+                const int kc = col[t0 + (key < S ? key : S - 1)];
+                v += relb[head * relw + (kc - qcol) + (relw >> 1)];
             }
-            if (col)
-                for (int j = threadIdx.x; j < kc; j += 256) cs[j] = col[t0 + k0 + j];
-            __syncthreads();
-            if (on) {
-                for (int j = 0; j < kc; ++j) {
-                    const uint4 *kp = reinterpret_cast<const uint4 *>(ks + (size_t)j * H + head * DH);
-                    float s = 0.f;
+            v = key < S ? v : -INFINITY;
+            sc[g] = v;
+            bm = fmaxf(bm, v);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        const float corr = __expf(m - mn);     // first block: exp(-inf) = 0
+        float ps = 0.f;
 #pragma unroll
-                    for (int e = 0; e < DH / 8; ++e) {
-                        const uint4 kv = kp[e];
-                        const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+        for (int g = 0; g < 16; ++g) {
+            sc[g] = __expf(sc[g] - mn);
+            ps += sc[g];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * corr + ps;
+        m = mn;
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            s = fmaf(__uint_as_float(q2[4 * e + u] << 16), __uint_as_float(kw[u] << 16), s);
-                            s = fmaf(__uint_as_float(q2[4 * e + u] & 0xffff0000u),
-                                     __uint_as_float(kw[u] & 0xffff0000u), s);
-                        }
-                    }
-                    s *= scale;
-                    if (relb) s += relb[head * relw + (cs[j] - qcol) + (relw >> 1)];
-                    if (s > mx) {
-                        const float corr = __expf(mx - s);
-                        l *= corr;
+        for (int ob = 0; ob < OT; ++ob)
 #pragma unroll
-                        for (int e = 0; e < DH; ++e) acc[e] *= corr;
-                        mx = s;
-                    }
-                    const float p = __expf(s - mx);
-                    l += p;
-                    const uint4 *vp = reinterpret_cast<const uint4 *>(vs + (size_t)j * H + head * DH);
+            for (int g = 0; g < 16; ++g) o[ob][g] *= corr;
+        // P^T fragments: k-step s takes accumulator registers 8s..8s+7
+        bf16x8 pf[2];
 #pragma unroll
-                    for (int e = 0; e < DH / 8; ++e) {
-                        const uint4 vv = vp[e];
-                        const uint32_t vw[4] = {vv.x, vv.y, vv.z, vv.w};
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            acc[8 * e + 2 * u] = fmaf(p, __uint_as_float(vw[u] << 16), acc[8 * e + 2 * u]);
-                            acc[8 * e + 2 * u + 1] = fmaf(p, __uint_as_float(vw[u] & 0xffff0000u), acc[8 * e + 2 * u + 1]);
-                        }
-                    }
+            for (int j = 0; j < 8; ++j) pf[s][j] = (__bf16)sc[8 * s + j];
+        // V^T fragments gathered in the matching k order
+#pragma unroll
+        for (int ob = 0; ob < OT; ++ob) {
+            const int i = ob * 32 + r;
+            const bool iv = i < DH;
+            const bf16_t *vp = qkv + 2 * H + head * DH + (iv ? i : 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 vf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = k0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+                    const int tv = t0 + (key < S ? key : S - 1);
+                    const bf16_t raw = vp[tv * H3];
+                    vf[j] = __builtin_bit_cast(__bf16, (bf16_t)(iv ? raw : (bf16_t)0));
+                }
+                o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[ob], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < S) {
+        const float inv = 1.0f / l;
+        bf16_t *op = ctx + (int64_t)(t0 + qi) * H + head * DH + 4 * h;
+#pragma unroll
+        for (int ob = 0; ob < OT; ++ob)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int i = ob * 32 + 8 * gq;  // + 4h + (0..3)
+                if (i + 4 * h < DH) {
+                    uint2 w;
+                    w.x = pack_bf16x2(o[ob][4 * gq] * inv, o[ob][4 * gq + 1] * inv);
+                    w.y = pack_bf16x2(o[ob][4 * gq + 2] * inv, o[ob][4 * gq + 3] * inv);
+                    *reinterpret_cast<uint2 *>(op + i) = w;
                 }
             }
-        }
-        if (on) {
-            const float inv = 1.0f / l;
-            uint4 *op = reinterpret_cast<uint4 *>(ctx + (int64_t)(t0 + qi) * H + head * DH);
-#pragma unroll
-            for (int e = 0; e < DH / 8; ++e) {
-                uint4 o;
-                o.x = pack_bf16x2(acc[8 * e] * inv, acc[8 * e + 1] * inv);
-                o.y = pack_bf16x2(acc[8 * e + 2] * inv, acc[8 * e + 3] * inv);
-                o.z = pack_bf16x2(acc[8 * e + 4] * inv, acc[8 * e + 5] * inv);
-                o.w = pack_bf16x2(acc[8 * e + 6] * inv, acc[8 * e + 7] * inv);
-                op[e] = o;
-            }
-        }
     }
 }
 
@@ -657,14 +683,23 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
         if (H == 64) EMBED(1); else if (H == 384) EMBED(6); else EMBED(12);
 #undef EMBED
         TSIM_HIP_CHECK(hipGetLastError());
-        const int KC = H <= 384 ? 32 : 16;
-        const size_t att_lds = (size_t)KC * H * 2 * 2 + KC * 4;
         const float scale = 1.0f / sqrtf((float)dh);
-        const int32_t *col = c.arch == TSIM_ARCH_MPNET ? (tok_col ? tok_col : tok_pos) : nullptr;
+        const bool rel = c.arch == TSIM_ARCH_MPNET;
+        const int32_t *col = rel ? (tok_col ? tok_col : tok_pos) : nullptr;
+        const int qblocks = (max_len + 31) / 32 > 0 ? (max_len + 31) / 32 : 1;
+        const dim3 agrid((unsigned)B, (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
         for (int l = 0; l < c.num_layers; ++l) {
             const tsim_encoder::Layer &L = e->layers[l];
             if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
-#define ATT(D) hipLaunchKernelGGL(attention_kernel<D>, dim3(B), dim3(256), att_lds, st, e->qkv, cu_seqlens, col, e->relb, e->relw, H, c.heads, scale, KC, e->ctx)
+#define ATT(D)                                                                                                 \
+    do {                                                                                                       \
+        if (rel)                                                                                               \
+            hipLaunchKernelGGL((attention_kernel<D, true>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col,  \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+        else                                                                                                   \
+            hipLaunchKernelGGL((attention_kernel<D, false>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col, \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+    } while (0)
             if (dh == 16) ATT(16); else if (dh == 32) ATT(32); else ATT(64);
 #undef ATT
             TSIM_HIP_CHECK(hipGetLastError());

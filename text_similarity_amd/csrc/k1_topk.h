@@ -2,6 +2,9 @@
 // Included by k1_kl16.hip / k1_kl32.hip (one translation unit per list length so they build in parallel).
 #pragma once
 #include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -48,12 +51,15 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     }
 }
 
-template <int D, int NWAVES>
+template <int D, int NWAVES, int QW>
 constexpr int k1_lds_bytes() {
-    return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * K1_QCAP * 64 * 8;
+    return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
 }
 
-template <int D, int NWAVES, int KL>
+// QW = query sets (of 32) resident per wave.  QW = 1: 8 waves x 32 queries, two waves per SIMD.  QW = 2: 4 waves x
+// 64 queries, one wave per SIMD with the whole 512-register file: every corpus fragment read from LDS feeds two
+// MFMAs, halving LDS traffic and per-tile fixed costs.  Both serve 256 queries per workgroup.
+template <int D, int NWAVES, int QW, int KL>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, const float *__restrict__ thr_in, float *__restrict__ part_s,
@@ -66,6 +72,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     constexpr int PIECES = STAGE_BYTES / 1024;         // 1-KiB LDS-DMA wave-instructions per stage
     static_assert(PIECES % NWAVES == 0, "stage must split evenly over the waves");
     constexpr int PPW = PIECES / NWAVES;
+    constexpr int QPW = 32 * QW;                       // queries per wave
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,23 +90,28 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const int64_t row0 = (int64_t)chunk * rows_per_chunk;
     const int crows = (int)(((N - row0) < (int64_t)rows_per_chunk) ? (N - row0) : (int64_t)rows_per_chunk);
     const int ntiles = (crows + K1_TILE_ROWS - 1) / K1_TILE_ROWS;
-    const int q0 = qb * (NWAVES * 32) + wave * 32;
+    const int q0 = qb * (NWAVES * QPW) + wave * QPW;
     const bool wave_on = q0 < Q;  // wave-uniform: waves past the last query only help staging
-    const int qrow = (q0 + r < Q) ? (q0 + r) : (Q - 1);
 
-    // ---- resident query fragments: B[k = 8h + j][col r] of k-step s = eq[q0 + r][16 s + 8 h + j]
-    bf16x8 bq[KSTEPS];
-    {
+    // ---- resident query fragments: B[k = 8h + j][col r] of k-step s = eq[q0 + 32u + r][16 s + 8 h + j]
+    bf16x8 bq[QW][KSTEPS];
+    float thr[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) {
+        const int qrow = (q0 + 32 * u + r < Q) ? (q0 + 32 * u + r) : (Q - 1);
         const bf16_t *qp = eq + (int64_t)qrow * D + 8 * h;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) bq[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        thr[u] = thr_in ? thr_in[qrow] : -INFINITY;
     }
-    float thr = thr_in ? thr_in[qrow] : -INFINITY;
     // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
     // and is waited for with counted vmcnt (cdna_hip_programming.md §5, "Three .s-level traps" (b)).
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bq[s]));
-    asm volatile("" : "+v"(thr));
+    for (int u = 0; u < QW; ++u) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bq[u][s]));
+        asm volatile("" : "+v"(thr[u]));
+    }
 
     // ---- LDS-DMA source offsets.  LDS image of a stage = the 32 rows back to back (row-major, 16-byte
     // slots), slot c of row rr holding source chunk c ^ (rr & 15): the XOR makes the ds_read_b128 of the
@@ -130,31 +142,68 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) aoff[bb] = r * ROWB + (((2 * bb + h) ^ x) << 4);
 
-    float ls[KL];
-    int li[KL];
+    float ls[QW][KL];
+    int li[QW][KL];
+    int cnt[QW];
 #pragma unroll
-    for (int j = 0; j < KL; ++j) {
-        ls[j] = -INFINITY;
-        li[j] = -1;
+    for (int u = 0; u < QW; ++u) {
+        cnt[u] = 0;
+#pragma unroll
+        for (int j = 0; j < KL; ++j) {
+            ls[u][j] = -INFINITY;
+            li[u][j] = -1;
+        }
     }
-    int cnt = 0;
-    // Per-lane candidate queue in LDS: entry p of this lane at qaddr + p*512 (lanes interleaved, 8 B each).
-    // Accessed with inline asm: hipcc would otherwise drain the LDS-DMA ring (s_waitcnt vmcnt(0)) before
-    // every ordinary LDS access that might alias it; the queue never overlaps the staging buffers.
-    const uint32_t qaddr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) +
-                           K1_NSTAGE * STAGE_BYTES + wave * (K1_QCAP * 64 * 8) + lane * 8;
+    // Per-lane candidate queues in LDS (one per query set): entry p of this lane at qaddr + p*512 (lanes
+    // interleaved, 8 B each).  Accessed with inline asm: hipcc would otherwise drain the LDS-DMA ring
+    // (s_waitcnt vmcnt(0)) before every ordinary LDS access that might alias it; the queues never overlap the
+    // staging buffers.
+    const uint32_t qaddr0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) +
+                            K1_NSTAGE * STAGE_BYTES + wave * (QW * K1_QCAP * 64 * 8) + lane * 8;
 
-    auto drain = [&]() {
+    auto drain = [&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
 #pragma unroll 1
         for (int p = 0; p < K1_QCAP; ++p) {
-            if (!__any(p < cnt)) break;
+            if (!__any(p < cnt[u])) break;
             uint64_t e;
             asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(qaddr + p * 512) : "memory");
-            const float s = (p < cnt) ? __uint_as_float((uint32_t)e) : -INFINITY;
-            list_insert<KL>(ls, li, s, (int)(e >> 32));
+            const float s = (p < cnt[u]) ? __uint_as_float((uint32_t)e) : -INFINITY;
+            list_insert<KL>(ls[u], li[u], s, (int)(e >> 32));
         }
-        cnt = 0;
-        thr = fmaxf(thr, ls[KL - 1]);
+        cnt[u] = 0;
+        thr[u] = fmaxf(thr[u], ls[u][KL - 1]);
+    };
+
+    auto filter = [&](auto uc, f32x16 &acc, int t) {
+        constexpr int u = decltype(uc)::value;
+        const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
+        const int trow = t * K1_TILE_ROWS + 4 * h;  // local (chunk-relative) row of acc[0]
+        if ((t + 1) * K1_TILE_ROWS > crows) {       // ragged last tile: rows past the chunk never compete
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (trow + (g & 3) + 8 * (g >> 2) >= crows) acc[g] = -INFINITY;
+        }
+        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int g = 3; g < 15; g += 2) m = fmaxf(fmaxf(m, acc[g]), acc[g + 1]);
+        m = fmaxf(m, acc[15]);
+        if (__any(m > thr[u])) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const bool p = acc[g] > thr[u];
+                if (__any(p)) {
+                    if (p) {
+                        const uint64_t e = (uint64_t)__float_as_uint(acc[g]) |
+                                           ((uint64_t)(uint32_t)(trow + (g & 3) + 8 * (g >> 2)) << 32);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(qaddr + cnt[u] * 512), "v"(e) : "memory");
+                        cnt[u]++;
+                    }
+                    if (__any(cnt[u] == K1_QCAP)) drain(uc);
+                }
+            }
+        }
     };
 
     issue_tile(0, 0);
@@ -166,37 +215,19 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         issue_tile(t + 2, (stage + 2) % K1_NSTAGE);
         if (!wave_on) return;
         const char *abase = smem + stage * STAGE_BYTES;
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc[QW];
+#pragma unroll
+        for (int u = 0; u < QW; ++u)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[u][g] = 0.f;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[s], acc, 0, 0, 0);
-        }
-        const int trow = t * K1_TILE_ROWS + 4 * h;  // local (chunk-relative) row of acc[0]
-        if ((t + 1) * K1_TILE_ROWS > crows) {       // ragged last tile: rows past the chunk never compete
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                if (trow + (g & 3) + 8 * (g >> 2) >= crows) acc[g] = -INFINITY;
+            for (int u = 0; u < QW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[u][s], acc[u], 0, 0, 0);
         }
-        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
-#pragma unroll
-        for (int g = 3; g < 15; g += 2) m = fmaxf(fmaxf(m, acc[g]), acc[g + 1]);
-        m = fmaxf(m, acc[15]);
-        if (__any(m > thr)) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const bool p = acc[g] > thr;
-                if (__any(p)) {
-                    if (p) {
-                        const uint64_t e = (uint64_t)__float_as_uint(acc[g]) |
-                                           ((uint64_t)(uint32_t)(trow + (g & 3) + 8 * (g >> 2)) << 32);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(qaddr + cnt * 512), "v"(e) : "memory");
-                        cnt++;
-                    }
-                    if (__any(cnt == K1_QCAP)) drain();
-                }
-            }
-        }
+        filter(std::integral_constant<int, 0>{}, acc[0], t);
+        if constexpr (QW > 1) filter(std::integral_constant<int, 1>{}, acc[QW - 1], t);
     };
 
     int t = 0;
@@ -210,34 +241,51 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
 
     if (wave_on) {
-        drain();
-        if (q0 + r < Q) {
-            const int P2 = nchunks * 2;
-            const int64_t o = ((int64_t)(q0 + r) * P2 + chunk * 2 + h) * KL;
-            const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
+        const int P2 = nchunks * 2;
+        const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
+        auto flush = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            drain(uc);
+            if (q0 + 32 * u + r < Q) {
+                const int64_t o = ((int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h) * KL;
 #pragma unroll
-            for (int j = 0; j < KL; j += 4) {
-                *reinterpret_cast<float4 *>(part_s + o + j) = make_float4(ls[j], ls[j + 1], ls[j + 2], ls[j + 3]);
-                int4 iv;
-                iv.x = li[j] < 0 ? -1 : li[j] + base;
-                iv.y = li[j + 1] < 0 ? -1 : li[j + 1] + base;
-                iv.z = li[j + 2] < 0 ? -1 : li[j + 2] + base;
-                iv.w = li[j + 3] < 0 ? -1 : li[j + 3] + base;
-                *reinterpret_cast<int4 *>(part_i + o + j) = iv;
+                for (int j = 0; j < KL; j += 4) {
+                    *reinterpret_cast<float4 *>(part_s + o + j) =
+                        make_float4(ls[u][j], ls[u][j + 1], ls[u][j + 2], ls[u][j + 3]);
+                    int4 iv;
+                    iv.x = li[u][j] < 0 ? -1 : li[u][j] + base;
+                    iv.y = li[u][j + 1] < 0 ? -1 : li[u][j + 1] + base;
+                    iv.z = li[u][j + 2] < 0 ? -1 : li[u][j + 2] + base;
+                    iv.w = li[u][j + 3] < 0 ? -1 : li[u][j + 3] + base;
+                    *reinterpret_cast<int4 *>(part_i + o + j) = iv;
+                }
             }
-        }
+        };
+        flush(std::integral_constant<int, 0>{});
+        if constexpr (QW > 1) flush(std::integral_constant<int, 1>{});
     }
 }
 
 struct TopkPlan {
-    int nqb, nchunks, rows_per_chunk, P2, KL, nwaves;
+    int nqb, nchunks, rows_per_chunk, P2, KL, qpb /* queries per workgroup */, variant;
     size_t part_elems;
 };
 
+// tuning switch (TSIM_K1_VARIANT=1 selects the 8-wave x 32-query kernel at d = 384; default 2 = 4 waves x 64 queries)
+static inline int k1_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("TSIM_K1_VARIANT");
+        v = (e && e[0] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
 static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     p->KL = k <= 12 ? 16 : 32;
-    p->nwaves = D <= 384 ? 8 : 4;
-    const int qpb = p->nwaves * 32;
+    p->variant = k1_variant();
+    p->qpb = D <= 384 ? 256 : 128;
+    const int qpb = p->qpb;
     p->nqb = (int)((Q + qpb - 1) / qpb);
     // enough workgroups to fill 256 CUs a few times over, but chunks as long as possible: the per-lane
     // selection cost falls with stream length (candidates ~ KL*ln(n/KL))
@@ -255,11 +303,11 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int KL>
+template <int D, int NWAVES, int QW, int KL>
 static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                      float *part_s, int *part_i, hipStream_t st) {
-    constexpr int lds = k1_lds_bytes<D, NWAVES>();
-    auto kern = cos_topk_partial_kernel<D, NWAVES, KL>;
+    constexpr int lds = k1_lds_bytes<D, NWAVES, QW>();
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -277,15 +325,16 @@ template <int KL>
 static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                         float *part_s, int *part_i, hipStream_t st) {
     switch (D) {
-        case 128: return launch_k1<128, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 256: return launch_k1<256, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 384: return launch_k1<384, 8, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 512: return launch_k1<512, 4, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 768: return launch_k1<768, 4, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 128: return launch_k1<128, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 256: return launch_k1<256, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 384:
+            if (p.variant == 1) return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+            return launch_k1<384, 4, 2, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 512: return launch_k1<512, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 768: return launch_k1<768, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
     }
 }
-
 
 int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                    float *part_s, int *part_i, hipStream_t st);

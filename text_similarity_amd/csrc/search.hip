@@ -344,6 +344,13 @@ extern "C" int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d,
     return TSIM_OK;
 }
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+extern "C" void tsim_time_next_topk(void *start_event, void *stop_event) {
+    g_ev_start = reinterpret_cast<hipEvent_t>(start_event);
+    g_ev_stop = reinterpret_cast<hipEvent_t>(stop_event);
+}
+
 extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) {
     if (Q <= 0 || N <= 0 || k <= 0 || k > 28) return 0;
     // the plan depends on the padded width only through the wave count; take the larger (4-wave) layout
@@ -372,9 +379,13 @@ extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64
     float *part_s = reinterpret_cast<float *>(workspace);
     int *part_i = reinterpret_cast<int *>(part_s + p.part_elems);
     hipStream_t st = as_stream(stream);
+    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));
     int rc = p.KL == 16 ? k1_launch_kl16(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, st)
                         : k1_launch_kl32(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, st);
     if (rc) return rc;
+    if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
     const unsigned grid = (unsigned)((Q + 3) / 4);
     if (p.KL == 16)
         hipLaunchKernelGGL(cos_topk_finalize_kernel<16>, dim3(grid), dim3(256), 0, st, part_s, part_i, p.P2, Q,

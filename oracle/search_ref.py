@@ -31,12 +31,49 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
     return np.where(np.isnan(x), x, r.astype(np.uint32).view(np.float32)).astype(np.float32)
 
 
-def l2_normalize(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
-    """x / max(||x||, eps) in float32 (row-wise): the per-operand clamp of torch>=1.12
-    cosine_similarity; a zero row stays zero, so its cosine with anything is 0."""
+def f64_to_bf16(v: np.ndarray) -> np.ndarray:
+    """float64 -> nearest bfloat16 (ties to even) with a single rounding, returned as bf16-exact float32.
+    Same algorithm as text_similarity_amd/csrc/common.h f64_to_bf16: round to float32, and where that landed exactly on
+    a bf16 midpoint step one float ulp back towards the true value before the final ties-to-even rounding."""
+    v = np.asarray(v, dtype=np.float64)
+    f = v.astype(np.float32)
+    u = f.view(np.uint32).copy()
+    mid = (u & np.uint32(0xFFFF)) == np.uint32(0x8000)
+    fd, av = np.abs(f.astype(np.float64)), np.abs(v)
+    u = np.where(mid & (av < fd), u - np.uint32(1), u)
+    u = np.where(mid & (av > fd), u + np.uint32(1), u).astype(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.astype(np.uint32).view(np.float32).reshape(v.shape)
+
+
+def l2_normalize_f64(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """x * (1 / max(||x||, eps)) in float64 (rows).  This is torch>=1.12 cosine_similarity's per-operand clamp (a zero
+    row stays zero, so its cosine with anything is 0: SURVEY.md A7).  The sum of squares follows the kernel's order
+    exactly (text_similarity_amd/csrc/common.h canonical_inv_norm): 64 lane partials over j = lane, lane+64, ... in
+    element order, then an xor butterfly 32, 16, .., 1 — so GPU and oracle agree bit for bit, not merely to rounding."""
     x = np.asarray(x, dtype=np.float32)
-    n = np.sqrt((x.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32)
-    return (x / np.maximum(n, np.float32(eps))).astype(np.float32)
+    rows, d = x.shape
+    pad = (-d) % 64
+    xd = np.concatenate([x.astype(np.float64), np.zeros((rows, pad))], axis=1).reshape(rows, -1, 64)
+    part = np.zeros((rows, 64), dtype=np.float64)
+    for i in range(xd.shape[1]):
+        part = part + xd[:, i, :] * xd[:, i, :]          # products of float32 are exact in float64: fma == mul+add
+    lanes = np.arange(64)
+    for o in (32, 16, 8, 4, 2, 1):
+        part = part + part[:, lanes ^ o]
+    inv = 1.0 / np.maximum(np.sqrt(part[:, :1]), np.float64(np.float32(eps)))
+    return x.astype(np.float64) * inv
+
+
+def l2_normalize(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """float32 view of l2_normalize_f64 (for comparisons with float32 references)."""
+    return l2_normalize_f64(x, eps).astype(np.float32)
+
+
+def unit_rows(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """The canonical search operand: L2-normalised rows rounded once to bf16 (bf16-exact float32) — what
+    tsim_l2norm_rows and the encoder's fused pooling epilogue store."""
+    return f64_to_bf16(l2_normalize_f64(x, eps))
 
 
 def cosine_similarity_rows(x: np.ndarray, y: np.ndarray, eps: float = 1e-8) -> np.ndarray:
@@ -128,10 +165,10 @@ def mining_search(query_emb: np.ndarray, corpus_emb: np.ndarray, k: int, chunk: 
     """search_pipeline.py:60-89 as intended: for each corpus chunk, each query row is
     scored against every chunk row with cosine_similarity and the k best are kept; chunks are merged.
     Inputs float32 un-normalised embeddings; scoring on bf16-rounded unit rows like the GPU path."""
-    qn = bf16_round(l2_normalize(query_emb))
+    qn = unit_rows(query_emb)
     vs, ix = [], []
     for s in range(0, corpus_emb.shape[0], chunk):
-        cn = bf16_round(l2_normalize(corpus_emb[s:s + chunk]))
+        cn = unit_rows(corpus_emb[s:s + chunk])
         v, i = cosine_topk(qn, cn, k, idx_offset=s)
         vs.append(v)
         ix.append(i)

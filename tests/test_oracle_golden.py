@@ -146,3 +146,18 @@ def test_e2e_config1_encode_and_search():
     np.testing.assert_allclose(v, g["top10_values"][:50], rtol=0, atol=3e-7)
     agree = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(i.tolist(), g["top10_indices"][:50].tolist())])
     assert agree > 0.99
+
+
+def test_f64_to_bf16_is_a_single_correct_rounding():
+    """Values a hair below / above a bf16 midpoint must NOT be dragged onto the midpoint by an intermediate float32
+    rounding (they would then follow the ties-to-even rule instead of their true side)."""
+    lo, hi = np.float32(1.0), np.float32(1.0078125)           # neighbouring bf16 values; midpoint 1.00390625
+    mid = np.float64(1.00390625)
+    eps = 2.0 ** -40
+    got = search_ref.f64_to_bf16(np.array([mid - eps, mid + eps, mid, 1.01171875, 1.01171875 + eps, -mid + eps]))
+    assert got.tolist() == [lo, hi, lo, np.float32(1.015625), np.float32(1.015625), -lo]
+    x = np.random.default_rng(0).standard_normal(10000)
+    ref = search_ref.bf16_round(x.astype(np.float32))          # agrees away from the double-rounding cases
+    assert (search_ref.f64_to_bf16(x) != ref).mean() < 1e-3
+    u = search_ref.unit_rows(np.random.default_rng(1).standard_normal((7, 100)).astype(np.float32))
+    assert np.array_equal(u, search_ref.bf16_round(u)) and abs(float((u[0].astype(np.float64) ** 2).sum()) - 1) < 2e-3

@@ -81,8 +81,8 @@ def test_anisotropic_scores_near_ties():
     base = presets.normal("aniso/base", 384)
     c = base[None, :] + 0.05 * presets.normal("aniso/c", 6000 * 384).reshape(6000, 384)
     q = base[None, :] + 0.05 * presets.normal("aniso/q", 50 * 384).reshape(50, 384)
-    cu = search_ref.bf16_round(search_ref.l2_normalize(c))
-    qu = search_ref.bf16_round(search_ref.l2_normalize(q))
+    cu = search_ref.unit_rows(c)
+    qu = search_ref.unit_rows(q)
     _check_exact(qu, cu, 10)
 
 
@@ -108,21 +108,25 @@ def test_self_search_full_size_properties():
     np.testing.assert_array_equal(s.cpu().numpy()[sel], rs)
 
 
-def test_l2norm_rows_matches_oracle():
+def test_l2norm_rows_matches_oracle_bit_exact():
     x = presets.normal("l2/x", 1000 * 384).reshape(1000, 384) * 3.0
     x[7] = 0.0
+    x[8] = 1e-12        # norm below eps: divided by eps, not by its norm
     u = ops.l2norm_rows(torch.from_numpy(x).to(DEV))
     torch.cuda.synchronize()
     got = u[:, :384].float().cpu().numpy()
-    ref = search_ref.bf16_round(search_ref.l2_normalize(x))
-    ulp = np.abs(ref) * 2.0 ** -7 + 1e-30
-    assert (np.abs(got - ref) <= ulp).all()           # at most one bf16 ulp (norm summed in a different order)
-    assert (got != ref).mean() < 1e-3
+    ref = search_ref.unit_rows(x)
+    np.testing.assert_array_equal(got, ref)
     assert (got[7] == 0).all() and (u[:, 384:] == 0).all()
     xb = torch.from_numpy(x).to(torch.bfloat16).to(DEV)
     ub = ops.l2norm_rows(xb)
-    refb = search_ref.bf16_round(search_ref.l2_normalize(xb.float().cpu().numpy()))
-    assert (np.abs(ub[:, :384].float().cpu().numpy() - refb) <= np.abs(refb) * 2.0 ** -7 + 1e-30).all()
+    refb = search_ref.unit_rows(xb.float().cpu().numpy())
+    np.testing.assert_array_equal(ub[:, :384].float().cpu().numpy(), refb)
+    # narrow rows (d = 100, not a multiple of 64) and the padded tail
+    y = presets.normal("l2/y", 33 * 100).reshape(33, 100)
+    uy = ops.l2norm_rows(torch.from_numpy(y).to(DEV))
+    np.testing.assert_array_equal(uy[:, :100].float().cpu().numpy(), search_ref.unit_rows(y))
+    assert uy.shape[1] == 128 and (uy[:, 100:] == 0).all()
 
 
 def test_topk_merge_matches_unsharded():

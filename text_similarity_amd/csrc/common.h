@@ -57,6 +57,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Canonical row scale for unit rows, reproducible bit for bit on the host (oracle/search_ref.l2_normalize):
+// sum of squares in float64 (each lane's partial in element order j = lane, lane+64, ..., then an xor butterfly
+// 32,16,..,1 — every lane ends with the same bits), inv = 1 / max(sqrt(ss), eps) in float64; an element is then
+// double(x) * inv rounded ONCE to bf16 (f64_to_bf16).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double canonical_inv_norm(double lane_partial_ss, float eps) {
+    const double ss = wave_sum_f64(lane_partial_ss);
+    return 1.0 / fmax(sqrt(ss), (double)eps);
+}
+// float64 -> bf16 with ONE correct rounding (nearest, ties to even).  Going through float32 would round twice: a
+// value within half a float ulp of a bf16 midpoint lands ON the midpoint and the tie rule then decides.  The
+// midpoint case is detected on the float bits and undone by stepping one float ulp back towards the true value.
+__device__ __forceinline__ bf16_t f64_to_bf16(double v) {
+    const float f = (float)v;
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;  // NaN
+    if ((u & 0xffffu) == 0x8000u) {
+        const double fd = fabs((double)f), av = fabs(v);
+        if (av < fd) u -= 1u;
+        else if (av > fd) u += 1u;
+    }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ bf16_t canonical_unit_elem(float x, double inv) { return f64_to_bf16((double)x * inv); }
+
 // async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,

@@ -449,17 +449,17 @@ __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restri
         for (int i = 0; i < VPL; ++i) s[i] += bf16_to_f32(x[(int64_t)t * H + lane + i * 64]);
     }
     const float den = fmaxf((float)(t1 - t0), 1e-9f);
-    float ss = 0.f;
+    double ss = 0.0;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         s[i] = s[i] / den;
-        ss = fmaf(s[i], s[i], ss);
+        ss = fma((double)s[i], (double)s[i], ss);
         if (pooled) pooled[(int64_t)b * H + lane + i * 64] = s[i];
     }
-    if (unit) {
-        const float nrm = fmaxf(sqrtf(wave_sum(ss)), 1e-8f);
+    if (unit) {  // identical bits to tsim_l2norm_rows(pooled): same element order, same float64 scale
+        const double inv = canonical_inv_norm(ss, 1e-8f);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) unit[(int64_t)b * ld_unit + lane + i * 64] = f32_to_bf16(s[i] / nrm);
+        for (int i = 0; i < VPL; ++i) unit[(int64_t)b * ld_unit + lane + i * 64] = canonical_unit_elem(s[i], inv);
         for (int j = H + lane; j < ld_unit; j += 64) unit[(int64_t)b * ld_unit + j] = 0;
     }
 }

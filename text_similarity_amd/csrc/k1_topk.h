@@ -51,6 +51,18 @@ __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], floa
     }
 }
 
+// float <-> int whose signed order equals the float order (for atomic max on scores)
+__device__ __forceinline__ int float_to_ordered(float f) {
+    const int k = __float_as_int(f);
+    return k >= 0 ? k : k ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+constexpr int K1_GTHR_INIT = (int)0x80808080;  // memset byte 0x80: below every finite score
+// bound published by another lane -> strict '>' filter value: the next float BELOW it (keeps equal scores eligible)
+__device__ __forceinline__ float import_threshold(int key) {
+    return key <= K1_GTHR_INIT ? -INFINITY : ordered_to_float(key - 1);
+}
+
 template <int D, int NWAVES, int QW>
 constexpr int k1_lds_bytes() {
     return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
@@ -62,7 +74,7 @@ constexpr int k1_lds_bytes() {
 template <int D, int NWAVES, int QW, int KL>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
-    int nchunks, int nqb, const float *__restrict__ thr_in, float *__restrict__ part_s,
+    int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
     int *__restrict__ part_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;                        // bytes per corpus row
@@ -96,13 +108,15 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     // ---- resident query fragments: B[k = 8h + j][col r] of k-step s = eq[q0 + 32u + r][16 s + 8 h + j]
     bf16x8 bq[QW][KSTEPS];
     float thr[QW];
+    int *gt[QW];   // this lane's query's shared threshold word
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
         const int qrow = (q0 + 32 * u + r < Q) ? (q0 + 32 * u + r) : (Q - 1);
         const bf16_t *qp = eq + (int64_t)qrow * D + 8 * h;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
-        thr[u] = thr_in ? thr_in[qrow] : -INFINITY;
+        gt[u] = gthr + qrow;
+        thr[u] = import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
     // and is waited for with counted vmcnt (cdna_hip_programming.md §5, "Three .s-level traps" (b)).
@@ -174,6 +188,13 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         }
         cnt[u] = 0;
         thr[u] = fmaxf(thr[u], ls[u][KL - 1]);
+        // Publish this lane's KL-th best and adopt the best bound any workgroup has published for the query:
+        // KL elements of the corpus score >= that bound, so nothing strictly below it can reach the query's final
+        // list.  A foreign bound is imported one ulp lower: rows of other lanes/workgroups are not "later in index
+        // order", so an equal score may still win its tie on the index.  Stale reads only make the filter weaker.
+        if (ls[u][KL - 1] > -INFINITY)
+            (void)__hip_atomic_fetch_max(gt[u], float_to_ordered(ls[u][KL - 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        thr[u] = fmaxf(thr[u], import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     };
 
     auto filter = [&](auto uc, f32x16 &acc, int t) {
@@ -271,12 +292,13 @@ struct TopkPlan {
     size_t part_elems;
 };
 
-// tuning switch (TSIM_K1_VARIANT=1 selects the 8-wave x 32-query kernel at d = 384; default 2 = 4 waves x 64 queries)
+// tuning switch: TSIM_K1_VARIANT=2 selects 4 waves x 64 queries at d = 384 (measured 1.5x slower: one wave per SIMD
+// cannot hide the LDS->MFMA latency); default 1 = 8 waves x 32 queries, two waves per SIMD
 static inline int k1_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("TSIM_K1_VARIANT");
-        v = (e && e[0] == '1') ? 1 : 2;
+        v = (e && e[0] == '2') ? 2 : 1;
     }
     return v;
 }
@@ -305,7 +327,7 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
 
 template <int D, int NWAVES, int QW, int KL>
 static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                     float *part_s, int *part_i, hipStream_t st) {
+                     float *part_s, int *part_i, int *gthr, hipStream_t st) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW>();
     auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL>;
     static bool attr_done = false;
@@ -316,29 +338,29 @@ static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_
     }
     const int grid = ((p.nchunks + 7) / 8) * 8 * p.nqb;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, eq, (int)Q, ec, N, p.rows_per_chunk,
-                       p.nchunks, p.nqb, (const float *)nullptr, part_s, part_i);
+                       p.nchunks, p.nqb, gthr, part_s, part_i);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
 
 template <int KL>
 static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                        float *part_s, int *part_i, hipStream_t st) {
+                        float *part_s, int *part_i, int *gthr, hipStream_t st) {
     switch (D) {
-        case 128: return launch_k1<128, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 256: return launch_k1<256, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+        case 128: return launch_k1<128, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 256: return launch_k1<256, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 384:
-            if (p.variant == 1) return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-            return launch_k1<384, 4, 2, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 512: return launch_k1<512, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
-        case 768: return launch_k1<768, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, st);
+            if (p.variant == 1) return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+            return launch_k1<384, 4, 2, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 512: return launch_k1<512, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 768: return launch_k1<768, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
     }
 }
 
 int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                   float *part_s, int *part_i, hipStream_t st);
+                   float *part_s, int *part_i, int *gthr, hipStream_t st);
 int k1_launch_kl32(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                   float *part_s, int *part_i, hipStream_t st);
+                   float *part_s, int *part_i, int *gthr, hipStream_t st);
 
 }  // namespace tsim

@@ -13,7 +13,8 @@
 namespace tsim {
 
 // =====================================================================================================
-// l2norm_rows: one wave per row.  HBM-bound: reads rows*d*(4|2) B, writes rows*ld_out*2 B.
+// l2norm_rows: one wave per row, canonical float64 scale (common.h).  HBM-bound: reads rows*d*(4|2) B, writes
+// rows*ld_out*2 B.
 // =====================================================================================================
 template <typename T>
 __device__ __forceinline__ float load_as_f32(const T *p);
@@ -30,18 +31,14 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ 
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T *xr = x + row * ld_in;
-    float ss = 0.f;
+    double ss = 0.0;
     for (int j = lane; j < d; j += 64) {
-        float v = load_as_f32<T>(xr + j);
-        ss = fmaf(v, v, ss);
+        const double v = (double)load_as_f32<T>(xr + j);
+        ss = fma(v, v, ss);
     }
-    ss = wave_sum(ss);
-    const float den = fmaxf(sqrtf(ss), eps);
+    const double inv = canonical_inv_norm(ss, eps);
     bf16_t *o = out + row * (int64_t)ld_out;
-    for (int j = lane; j < ld_out; j += 64) {
-        float v = j < d ? load_as_f32<T>(xr + j) / den : 0.f;
-        o[j] = f32_to_bf16(v);
-    }
+    for (int j = lane; j < ld_out; j += 64) o[j] = j < d ? canonical_unit_elem(load_as_f32<T>(xr + j), inv) : (bf16_t)0;
 }
 
 // =====================================================================================================
@@ -358,7 +355,7 @@ extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) 
     plan_topk(Q, N, 384, k, &a);
     plan_topk(Q, N, 768, k, &b);
     const size_t e = a.part_elems > b.part_elems ? a.part_elems : b.part_elems;
-    return e * 8 + 256;
+    return e * 8 + (size_t)Q * 4 + 256;
 }
 
 extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64_t N, int d, int ld, int k,
@@ -373,17 +370,19 @@ extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64
     TSIM_REQUIRE((((uintptr_t)eq | (uintptr_t)ec) & 15) == 0, "cosine_topk: embedding matrices must be 16-byte aligned");
     TopkPlan p;
     plan_topk(Q, N, ld, k, &p);
-    const size_t need = p.part_elems * 8;
+    const size_t need = p.part_elems * 8 + (size_t)Q * 4;
     if (!workspace || workspace_bytes < need)
         return fail(TSIM_ENOMEM, "cosine_topk: workspace %zu B < %zu B", workspace_bytes, need);
     float *part_s = reinterpret_cast<float *>(workspace);
     int *part_i = reinterpret_cast<int *>(part_s + p.part_elems);
+    int *gthr = part_i + p.part_elems;   // per-query shared threshold words, re-initialised every call
     hipStream_t st = as_stream(stream);
+    TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));
-    int rc = p.KL == 16 ? k1_launch_kl16(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, st)
-                        : k1_launch_kl32(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, st);
+    int rc = p.KL == 16 ? k1_launch_kl16(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, gthr, st)
+                        : k1_launch_kl32(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, gthr, st);
     if (rc) return rc;
     if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
     const unsigned grid = (unsigned)((Q + 3) / 4);

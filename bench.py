@@ -38,6 +38,21 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, Chip-
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 
 
+def measured_traffic(Q, n_local, d, k):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_k1_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, gfx950 x2 read correction).  Counters cannot be
+    read live from Python, so the number is reported only when this run's workload is the profiled one; else None."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k1_traffic.json")) as f:
+            t = json.load(f)
+        w = t["workload"]
+        if (w["queries_per_step"], w["corpus_rows_per_gpu"], w["d"], w["k"]) == (Q, n_local, d, k):
+            return t["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(preset: str, d: int, n_rows: int, k: int):
     """The oracle (CPU port of the reference path) on this box's host cores, bounded to ~10-30 s."""
     from oracle import encoder_ref
@@ -201,9 +216,10 @@ def main():
                        "encode_sentences_per_s_per_gpu": round(q_local / enc_ms * 1e3, 1),
                        "encode_tflops_per_gpu": round(enc_flops / enc_ms / 1e9, 1),
                        "search_mpairs_per_s_per_gpu": round(Q * n_local / srch_ms / 1e3, 1)},
-            "roofline": {"bound": "mfma", "kernel": "cos_topk_partial_kernel<384,8,16>",
+            "roofline": {"bound": "mfma", "kernel": "cos_topk_partial_kernel<384,8,1,16>",
                          "achieved": round(k1_flops / k1_ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k1_flops / k1_ms / 1e9 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(k1_flops / k1_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                         "traffic": measured_traffic(Q, n_local, d, k),
                          "launch_ms": round(k1_ms, 4), "flops_per_launch": k1_flops,
                          "hbm_stream_GBs": round(k1_stream_bytes / k1_ms / 1e6, 1),
                          "hbm_stream_frac": round(k1_stream_bytes / k1_ms / 1e6 / PEAK_HBM_GBS, 4), "query_block": 256},

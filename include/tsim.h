@@ -41,12 +41,13 @@ int tsim_version(void);
 const char *tsim_last_error(void);
 
 /* Row stride (elements) of the engine's internal bf16 embedding matrices for an embedding width d:
- * the smallest supported kernel width >= d (128, 256, 384, 512, 768 or 1024); 0 if d > 1024. */
+ * the smallest supported kernel width >= d (128, 256, 384, 512 or 768); 0 if d > 768. */
 int tsim_pad_dim(int d);
 
 /* ---------------------------------------------------------------------------------------------
  * A7  F.cosine_similarity operand preparation   /root/reference/src/pipeline/search_pipeline.py:77
- * out[r, :d] = bf16( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0.
+ * out[r, :d] = bf16( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0, evaluated canonically: float64 sum of
+ * squares in a fixed order, float64 reciprocal, one rounding float64 -> bf16 (oracle/search_ref.unit_rows is bit-identical).
  * torch divides each operand by max(norm, eps) with eps = 1e-8; a zero row stays zero, so its score
  * against anything is 0.  x_dtype is TSIM_F32 or TSIM_BF16, ld_in its row stride in elements. */
 int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in,

@@ -68,6 +68,16 @@ constexpr int k1_lds_bytes() {
     return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
 }
 
+// Measured on MI355X (gpurun r01, N = 1 M, d = 384, k = 10; profiles/README.md):
+//   * the same kernel with the selection removed runs Q = 4096 in 2.46 ms and Q = 16384 in 9.2 ms (1.28-1.37 PFLOP/s,
+//     ~54 % of the dense bf16 peak): that is the ceiling of this streaming structure;
+//   * the fast check (max3 tree + one compare per tile) costs 2-4 %; the slow path (queueing + drains, amplified by
+//     the per-tile workgroup barrier: one draining wave stalls eight) costs +33 % at Q = 4096, +24 % at Q = 16384 and
+//     3.9x at Q = 256, where per-lane streams are only ~1 k rows;
+//   * dropped variants: 4 waves x 64 queries at one wave per SIMD (1.5x slower: nothing hides LDS->MFMA latency);
+//     two independent 4-wave workgroups per CU (no gain at Q = 4096, 2x slower at Q = 16384); deferring tile t's
+//     filter into tile t+1's MFMA stream with ping-pong accumulators (1.2x slower: splits the stream into basic
+//     blocks); refreshing thresholds from the shared word every 16 tiles (no gain).
 // QW = query sets (of 32) resident per wave.  QW = 1: 8 waves x 32 queries, two waves per SIMD.  QW = 2: 4 waves x
 // 64 queries, one wave per SIMD with the whole 512-register file: every corpus fragment read from LDS feeds two
 // MFMAs, halving LDS traffic and per-tile fixed costs.  Both serve 256 queries per workgroup.
@@ -139,8 +149,20 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         src_row[i] = rr;
         src_off[i] = (cc ^ (rr & 15)) * 16;
     }
+    const char *src_base[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+        src_base[i] = reinterpret_cast<const char *>(ec) + (row0 + src_row[i]) * ROWB + src_off[i];
+    const int full_tiles = crows / K1_TILE_ROWS;   // tiles whose 32 rows all exist
     auto issue_tile = [&](int t, int stage) {
         const int tt = t < ntiles ? t : ntiles - 1;  // past-the-end tiles re-read the last one: keeps vmcnt uniform
+        if (tt < full_tiles) {
+            // tiles are contiguous in the corpus: per-lane base pointer + t * STAGE_BYTES
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                glds16(src_base[i] + (int64_t)tt * STAGE_BYTES, smem + stage * STAGE_BYTES + (wave * PPW + i) * 1024);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             int64_t gr = row0 + (int64_t)tt * K1_TILE_ROWS + src_row[i];
@@ -184,7 +206,8 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             uint64_t e;
             asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(qaddr + p * 512) : "memory");
             const float s = (p < cnt[u]) ? __uint_as_float((uint32_t)e) : -INFINITY;
-            list_insert<KL>(ls[u], li[u], s, (int)(e >> 32));
+            // entries were queued against an older (lower) threshold: most no longer beat the list tail
+            if (__any(s > ls[u][KL - 1])) list_insert<KL>(ls[u], li[u], s, (int)(e >> 32));
         }
         cnt[u] = 0;
         thr[u] = fmaxf(thr[u], ls[u][KL - 1]);
@@ -241,11 +264,34 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         for (int u = 0; u < QW; ++u)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[u][g] = 0.f;
+        if constexpr (QW == 1) {
+            // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step
+            // s, so an LDS read has PF MFMAs (PF*32 pipe cycles) to land; sched_group_barrier pins the interleave and
+            // the compiler's counted lgkmcnt waits follow from it.
+            constexpr int PF = 4;
+            bf16x8 fr[PF + 1];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
+            for (int i = 0; i < PF; ++i)
+                fr[i] = *reinterpret_cast<const bf16x8 *>(abase + aoff[i & 7] + (i >> 3) * 256);
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-            for (int u = 0; u < QW; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[u][s], acc[u], 0, 0, 0);
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + PF < KSTEPS) {
+                    const int n = s + PF;
+                    fr[n % (PF + 1)] = *reinterpret_cast<const bf16x8 *>(abase + aoff[n & 7] + (n >> 3) * 256);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % (PF + 1)], bq[0][s], acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
+#pragma unroll
+                for (int u = 0; u < QW; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[u][s], acc[u], 0, 0, 0);
+            }
         }
         filter(std::integral_constant<int, 0>{}, acc[0], t);
         if constexpr (QW > 1) filter(std::integral_constant<int, 1>{}, acc[QW - 1], t);
@@ -292,20 +338,9 @@ struct TopkPlan {
     size_t part_elems;
 };
 
-// tuning switch: TSIM_K1_VARIANT=2 selects 4 waves x 64 queries at d = 384 (measured 1.5x slower: one wave per SIMD
-// cannot hide the LDS->MFMA latency); default 1 = 8 waves x 32 queries, two waves per SIMD
-static inline int k1_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("TSIM_K1_VARIANT");
-        v = (e && e[0] == '2') ? 2 : 1;
-    }
-    return v;
-}
-
 static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     p->KL = k <= 12 ? 16 : 32;
-    p->variant = k1_variant();
+    p->variant = 1;
     p->qpb = D <= 384 ? 256 : 128;
     const int qpb = p->qpb;
     p->nqb = (int)((Q + qpb - 1) / qpb);
@@ -349,9 +384,7 @@ static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, c
     switch (D) {
         case 128: return launch_k1<128, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 256: return launch_k1<256, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 384:
-            if (p.variant == 1) return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-            return launch_k1<384, 4, 2, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 384: return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 512: return launch_k1<512, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 768: return launch_k1<768, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);

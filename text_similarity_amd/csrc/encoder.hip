@@ -13,6 +13,7 @@
 // biases and LayerNorm parameters float32.
 #include <math.h>
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -83,19 +84,20 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
-    // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output
-    // resolution).  ~14 VALU ops against ~30 for erff().
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output resolution),
+    // raw v_rcp_f32 / v_exp_f32 (1 ulp) with the constants folded: 14 VALU instructions (erff(): ~30; the same formula
+    // with an IEEE-correct reciprocal and a guarded exp: 29).  FFN1's epilogue is VALU-bound, so this matters.
+    //   1 - erf(|x|/sqrt2) = poly(t) * t * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)
+    //   gelu = hx + |hx| (1 - pe) with hx = x/2
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __expf(-z * z);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    const float erfv = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erfv);
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    const float pe = poly * t * e;
+    const float hx = 0.5f * x;
+    return fmaf(-fabsf(hx), pe, hx + fabsf(hx));
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -107,7 +109,7 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
     const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles) {
+    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles, int diag) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MT = TM / 32, NT = TN / 32;
     constexpr int RB = BK * 2;       // bytes per tile row
@@ -289,10 +291,152 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                     uint2 o;
                     o.x = pack_bf16x2(y0, y1);
                     o.y = pack_bf16x2(y2, y3);
-                    *reinterpret_cast<uint2 *>(out + m * N + n) = o;
+                    if (diag & 1) asm volatile("" ::"v"(o.x), "v"(o.y));   // DIAGNOSTIC: no stores
+                    else *reinterpret_cast<uint2 *>(out + m * N + n) = o;
                 }
             }
     }
+}
+
+// =====================================================================================================
+// GEMM with the activation operand RESIDENT IN REGISTERS (K = 384 layers of MiniLM: QKV and FFN1).
+//
+// At K = 384 a tiled GEMM spends its time in prologues and epilogues: six K-steps per output tile.  Here a workgroup
+// (8 waves) owns 256 tokens for the WHOLE layer: each wave loads its 32 token rows once as MFMA B fragments (K/16 x 4 =
+// 96 VGPRs) and then sweeps every output feature while W streams through LDS exactly like the corpus does in the
+// cosine kernel: 192-feature x 64-k tiles (24 KiB), 3-stage LDS-DMA ring, counted vmcnt, one raw s_barrier per tile, 24
+// MFMAs per tile and wave, XOR-swizzled image read with conflict-free ds_read_b128.  The W stream never restarts
+// between output tiles, so there is one prologue per 256 tokens instead of one per 128x128 tile.
+// Orientation as in gemm_bf16_kernel (token on the lane); the epilogue pairs the two half-waves with
+// v_permlane32_swap so every lane stores 16 contiguous bytes.
+// =====================================================================================================
+constexpr int XR_BN = 192, XR_BK = 64, XR_NSTAGE = 3;
+
+template <int K, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+                                                        const float *__restrict__ bias, bf16_t *__restrict__ out,
+                                                        int M, int N, int items_total) {
+    constexpr int KSTEPS = K / 16, KG = K / XR_BK;          // 24 k-steps, 6 k-groups
+    constexpr int STAGE = XR_BN * XR_BK * 2;                 // 24 KiB
+    constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;  // 24 pieces, 3 (8 waves) or 6 (4 waves) per wave
+    constexpr int NSUB = XR_BN / 32;                         // 6 feature sub-tiles of 32
+    constexpr int BMX = NW * 32;                             // tokens per block
+    static_assert(PIECES % NW == 0 && K % XR_BK == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ntiles = N / XR_BN;
+    // persistent workgroups: a contiguous range of work items (token block of 32*NW, feature tile of 192), feature
+    // tile fastest, so a workgroup changes token block at most a couple of times and the load is balanced to one item
+    const int it0 = (int)((int64_t)items_total * blockIdx.x / gridDim.x);
+    const int it1 = (int)((int64_t)items_total * (blockIdx.x + 1) / gridDim.x);
+    const int total = (it1 - it0) * KG;                      // W tiles this workgroup streams
+    if (total <= 0) return;
+
+    int src_off[PPW];   // byte offset inside a W tile's source of this lane's 16 B
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int sl = (wave * PPW + i) * 64 + lane;
+        const int sr = sl >> 4, ch = (sl & 15) ^ (sr & 15);
+        const int row = sr * 2 + (ch >> 3), c = ch & 7;
+        src_off[i] = row * K * 2 + c * 16;
+    }
+    auto issue = [&](int tt, int stage) {
+        const int t2 = tt < total ? tt : total - 1;           // past-the-end: re-read the last tile (uniform vmcnt)
+        const int j = (it0 + t2 / KG) % ntiles, g = t2 % KG;
+        const char *base = reinterpret_cast<const char *>(W) + ((int64_t)j * XR_BN * K + g * XR_BK) * 2;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            glds16(base + src_off[i], smem + stage * STAGE + (wave * PPW + i) * 1024);
+    };
+    int aoff[NSUB];
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i) aoff[i] = ((i * 32 + r) >> 1) * 256;   // super-row base; chunk XOR added per ks
+    const int rodd = (r & 1) * 8;
+
+    bf16x8 bx[KSTEPS];   // resident activation fragments: B[k = 8h + j][col r] of k-step s = X[m0 + r][16 s + 8 h + j]
+    int cur_mb = -1, m0 = 0;
+    f32x16 acc[NSUB];
+#pragma unroll
+    for (int i = 0; i < NSUB; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
+
+    issue(0, 0);
+    issue(1, 1);
+    for (int tt = 0; tt < total; ++tt) {
+        const int stage = tt % XR_NSTAGE;
+        const int g = tt % KG;
+        const int item = it0 + tt / KG;
+        if (g == 0 && item / ntiles != cur_mb) {              // wave-uniform: new token block -> reload fragments
+            cur_mb = item / ntiles;
+            m0 = cur_mb * BMX + wave * 32;
+            const bf16_t *xp = X + (int64_t)(m0 + r) * K + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) bx[s] = *reinterpret_cast<const bf16x8 *>(xp + 16 * s);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retire these ordinary loads here
+        }
+        wait_vmcnt<PPW>();
+        __builtin_amdgcn_s_barrier();
+        issue(tt + 2, (stage + 2) % XR_NSTAGE);
+        const char *ws = smem + stage * STAGE;
+        // the k-group index selects which resident fragments to use: unrolled switch keeps bx[] in registers
+#pragma unroll
+        for (int gg = 0; gg < KG; ++gg) {
+            if (g == gg) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < NSUB; ++i) {
+                        const int sr = (i * 32 + r) >> 1;
+                        const int ch = (rodd + 2 * ks + h) ^ (sr & 15);
+                        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + aoff[i] + (ch << 4));
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bx[gg * 4 + ks], acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (g == KG - 1) {
+            // epilogue of output tile j: acc[i][q]: feature n0 + i*32 + (q&3) + 8*(q>>2) + 4*h, token m0 + r
+            const int n0 = (item % ntiles) * XR_BN;
+            const int64_t m = m0 + r;
+#pragma unroll
+            for (int i = 0; i < NSUB; ++i) {
+                uint32_t pk[8];   // pk[2*gq], pk[2*gq+1]: this lane's 4 features of group gq as packed bf16
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int n = n0 + i * 32 + 8 * gq + 4 * h;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
+                    float y0 = acc[i][4 * gq] + bv.x, y1 = acc[i][4 * gq + 1] + bv.y;
+                    float y2 = acc[i][4 * gq + 2] + bv.z, y3 = acc[i][4 * gq + 3] + bv.w;
+                    if constexpr (EPI == EPI_GELU) {
+                        y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
+                    }
+                    pk[2 * gq] = pack_bf16x2(y0, y1);
+                    pk[2 * gq + 1] = pack_bf16x2(y2, y3);
+                }
+                // lane (r,0) holds features 8gq+0..3, lane (r,1) features 8gq+4..7.  Swap so that the low half-wave
+                // owns features 8gq..8gq+7 of group gq (even gq) and the high half-wave those of group gq+1: one
+                // 16-byte store per lane and group pair (cdna_hip_programming.md T21).
+#pragma unroll
+                for (int gq = 0; gq < 4; gq += 2) {
+                    uint32_t a0 = pk[2 * gq], a1 = pk[2 * gq + 1], b0 = pk[2 * gq + 2], b1 = pk[2 * gq + 3];
+                    auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    a0 = s0[0]; b0 = s0[1]; a1 = s1[0]; b1 = s1[1];
+                    if (m < M) {
+                        uint4 o = make_uint4(a0, a1, b0, b1);
+                        *reinterpret_cast<uint4 *>(out + m * N + n0 + i * 32 + 8 * gq + 8 * h) = o;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+            }
+        }
+    }
+    wait_vmcnt<0>();
 }
 
 // =====================================================================================================
@@ -563,15 +707,46 @@ static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, cons
     if (N % BN != 0 || K % BK != 0) return fail(TSIM_EUNSUPPORTED, "gemm: N=%d K=%d not tileable by %dx%d", N, K, BN, BK);
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+    static int diag = -1;
+    if (diag < 0) { const char *e = getenv("TSIM_GEMM_DIAG"); diag = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, X, W, bias, res, gamma, beta, eps, out, M, N, K,
-                       mtiles, ntiles);
+                       mtiles, ntiles, diag);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
+template <int EPI, int NW>
+static int gemm_xres_nw(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
+    constexpr int lds = XR_NSTAGE * XR_BN * XR_BK * 2;
+    auto kern = gemm_xres_kernel<384, EPI, NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+    const int items = ((M + NW * 32 - 1) / (NW * 32)) * (N / XR_BN);
+    const int slots = 256 * (8 / NW);             // persistent workgroups: one (8 waves) or two (4 waves) per CU
+    const int grid = items < slots ? items : slots;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, X, W, bias, out, M, N, items);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
 
 template <int EPI>
+static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
+    static int nw = -1;
+    if (nw < 0) { const char *e = getenv("TSIM_XRES_WAVES"); nw = e ? atoi(e) : 8; }
+    if (nw == 4) return gemm_xres_nw<EPI, 4>(X, W, bias, out, M, N, st);
+    return gemm_xres_nw<EPI, 8>(X, W, bias, out, M, N, st);
+}
+
+template <int EPI>
 static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, int K,
                       hipStream_t st) {
+    static int use_xres = -1;
+    if (use_xres < 0) { const char *e = getenv("TSIM_GEMM_XRES"); use_xres = e ? atoi(e) : 1; }
+    if (use_xres && K == 384 && N % XR_BN == 0) return gemm_xres<EPI>(X, W, bias, out, M, N, st);
     if (N % 128 == 0)
         return launch_gemm<128, 128, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
     return launch_gemm<128, 64, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);

@@ -81,7 +81,10 @@ constexpr int k1_lds_bytes() {
 // QW = query sets (of 32) resident per wave.  QW = 1: 8 waves x 32 queries, two waves per SIMD.  QW = 2: 4 waves x
 // 64 queries, one wave per SIMD with the whole 512-register file: every corpus fragment read from LDS feeds two
 // MFMAs, halving LDS traffic and per-tile fixed costs.  Both serve 256 queries per workgroup.
-template <int D, int NWAVES, int QW, int KL>
+// MAXONLY = threshold pre-pass: no lists and no queues, every lane just keeps the maximum score of its sub-stream and
+// writes it to part_s[query][partition]; the KL-th largest of a query's block maxima (distinct rows by construction)
+// is a valid lower bound of its final KL-th best score (thr_select_kernel), with which the main pass starts.
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
@@ -125,8 +128,13 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         const bf16_t *qp = eq + (int64_t)qrow * D + 8 * h;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
-        gt[u] = gthr + qrow;
-        thr[u] = import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if constexpr (MAXONLY) {   // pre-pass: no thresholds (gthr is null)
+            gt[u] = nullptr;
+            thr[u] = -INFINITY;
+        } else {
+            gt[u] = gthr + qrow;
+            thr[u] = import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
     }
     // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
     // and is waited for with counted vmcnt (cdna_hip_programming.md §5, "Three .s-level traps" (b)).
@@ -220,6 +228,10 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         thr[u] = fmaxf(thr[u], import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     };
 
+    float bmax[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) bmax[u] = -INFINITY;
+
     auto filter = [&](auto uc, f32x16 &acc, int t) {
         constexpr int u = decltype(uc)::value;
         const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
@@ -233,6 +245,10 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
         for (int g = 3; g < 15; g += 2) m = fmaxf(fmaxf(m, acc[g]), acc[g + 1]);
         m = fmaxf(m, acc[15]);
+        if constexpr (MAXONLY) {
+            bmax[u] = fmaxf(bmax[u], m);
+            return;
+        }
         if (__any(m > thr[u])) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -312,6 +328,10 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
         auto flush = [&](auto uc) {
             constexpr int u = decltype(uc)::value;
+            if constexpr (MAXONLY) {
+                if (q0 + 32 * u + r < Q) part_s[(int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h] = bmax[u];
+                return;
+            }
             drain(uc);
             if (q0 + 32 * u + r < Q) {
                 const int64_t o = ((int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h) * KL;
@@ -338,6 +358,23 @@ struct TopkPlan {
     size_t part_elems;
 };
 
+// Pre-pass plan: block maxima over the first S rows.  S = 64 K rows (32 K when there are >= 4 query blocks), cut into
+// enough chunks to fill the chip; returns false when the corpus is too small for a pre-pass to pay.
+static inline bool plan_prepass(int64_t Q, int64_t N, const TopkPlan &mainp, TopkPlan *p) {
+    if (N < 262144) return false;
+    const int64_t S = mainp.nqb >= 4 ? 32768 : 65536;
+    int nch = 512 / mainp.nqb;
+    if (nch < 16) nch = 16;
+    if (nch > S / 64) nch = (int)(S / 64);
+    *p = mainp;
+    p->nchunks = nch;
+    p->rows_per_chunk = (int)(S / nch);
+    p->P2 = 2 * nch;
+    p->part_elems = (size_t)Q * p->P2;
+    return p->P2 >= 2 * mainp.KL;
+}
+constexpr int K1_PREPASS_MAX_P2 = 2048;
+
 static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     p->KL = k <= 12 ? 16 : 32;
     p->variant = 1;
@@ -360,11 +397,11 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int QW, int KL>
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false>
 static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW>();
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL>;
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -378,19 +415,22 @@ static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_
     return TSIM_OK;
 }
 
-template <int KL>
+template <int KL, bool MAXONLY = false>
 static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                         float *part_s, int *part_i, int *gthr, hipStream_t st) {
     switch (D) {
-        case 128: return launch_k1<128, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 256: return launch_k1<256, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 384: return launch_k1<384, 8, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 512: return launch_k1<512, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 768: return launch_k1<768, 4, 1, KL>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 128: return launch_k1<128, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 256: return launch_k1<256, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 384: return launch_k1<384, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 512: return launch_k1<512, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 768: return launch_k1<768, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
     }
 }
 
+// threshold pre-pass over the first rows of the corpus (block maxima only); defined in k1_kl16.hip
+int k1_launch_blockmax(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+                       float *bmax, hipStream_t st);
 int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                    float *part_s, int *part_i, int *gthr, hipStream_t st);
 int k1_launch_kl32(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,

@@ -6,6 +6,7 @@
 //   /root/reference/src/utils/metrics.py:81-101             cos_sim
 //   /root/reference/src/modules/modules.py:158-171          AvgPoolingStrategy.forward
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "k1_topk.h"
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
-    const int E = P2 * KL;
+    const int64_t E = (int64_t)P2 * KL;
     const float *ps = part_s + q * E;
     const int *pi = part_i + q * E;
 
@@ -90,16 +91,24 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
             }
         }
     };
-    int e = lane;
-    for (; e + 192 < E; e += 256) {  // 4 independent loads in flight per lane
-        const float s0 = ps[e], s1 = ps[e + 64], s2 = ps[e + 128], s3 = ps[e + 192];
-        const int i0 = pi[e], i1 = pi[e + 64], i2 = pi[e + 128], i3 = pi[e + 192];
-        consider(s0, i0);
-        consider(s1, i1);
-        consider(s2, i2);
-        consider(s3, i3);
+    // Lists are sorted and padded with (-inf, -1): a lane walks whole lists (list = lane, lane+64, ...), reads the
+    // first four row ids (16 B) and stops at the first pad.  With pre-pass thresholds most lists are empty, so this
+    // touches 16 B per list instead of its 8*KL bytes.
+    for (int l = lane; l < P2; l += 64) {
+        const float *lsrc = ps + (int64_t)l * KL;
+        const int *isrc = pi + (int64_t)l * KL;
+#pragma unroll 1
+        for (int j = 0; j < KL; j += 4) {
+            const int4 iv = *reinterpret_cast<const int4 *>(isrc + j);
+            if (iv.x < 0) break;
+            const float4 sv = *reinterpret_cast<const float4 *>(lsrc + j);
+            consider(sv.x, iv.x);
+            consider(sv.y, iv.y);
+            consider(sv.z, iv.z);
+            consider(sv.w, iv.w);
+            if (iv.w < 0) break;
+        }
     }
-    for (; e < E; e += 64) consider(ps[e], pi[e]);
 
     // 1b. KL rounds of a 64-way merge of the list heads; the winning lane pops its head
     float my_s = -INFINITY;  // lane t < KL ends up holding the t-th selected candidate
@@ -170,6 +179,42 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
         out_s[q * k + lane] = -INFINITY;
         out_i[q * k + lane] = -1;
     }
+}
+
+// =====================================================================================================
+// thr_select: gthr[q] = ordered-int form of the KL-th largest of the query's P2 block maxima (pre-pass output,
+// [Q][P2] floats).  One wave per query; KL rounds of (lane-local max, wave max, owner removes one instance).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void thr_select_kernel(const float *__restrict__ bmax, int P2, int64_t Q, int KL,
+                                                         int *__restrict__ gthr) {
+    constexpr int VPL = K1_PREPASS_MAX_P2 / 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < P2 ? bmax[q * P2 + e] : -INFINITY;
+    }
+    float best = -INFINITY;
+    for (int t = 0; t < KL; ++t) {
+        float lm = v[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i) lm = fmaxf(lm, v[i]);
+        best = wave_max(lm);
+        const unsigned long long owners = __ballot(lm == best);
+        if (lane == __ffsll((long long)owners) - 1) {   // one owner removes one instance
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const bool hit = !done && v[i] == best;
+                v[i] = hit ? -INFINITY : v[i];
+                done = done || hit;
+            }
+        }
+    }
+    if (lane == 0) gthr[q] = best > -INFINITY ? float_to_ordered(best) : K1_GTHR_INIT;
 }
 
 // =====================================================================================================
@@ -355,7 +400,7 @@ extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) 
     plan_topk(Q, N, 384, k, &a);
     plan_topk(Q, N, 768, k, &b);
     const size_t e = a.part_elems > b.part_elems ? a.part_elems : b.part_elems;
-    return e * 8 + (size_t)Q * 4 + 256;
+    return e * 8 + (size_t)Q * 4 + (size_t)Q * K1_PREPASS_MAX_P2 * 4 + 256;
 }
 
 extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64_t N, int d, int ld, int k,
@@ -370,14 +415,27 @@ extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64
     TSIM_REQUIRE((((uintptr_t)eq | (uintptr_t)ec) & 15) == 0, "cosine_topk: embedding matrices must be 16-byte aligned");
     TopkPlan p;
     plan_topk(Q, N, ld, k, &p);
-    const size_t need = p.part_elems * 8 + (size_t)Q * 4;
+    const size_t need = p.part_elems * 8 + (size_t)Q * 4 + (size_t)Q * K1_PREPASS_MAX_P2 * 4;
     if (!workspace || workspace_bytes < need)
         return fail(TSIM_ENOMEM, "cosine_topk: workspace %zu B < %zu B", workspace_bytes, need);
     float *part_s = reinterpret_cast<float *>(workspace);
     int *part_i = reinterpret_cast<int *>(part_s + p.part_elems);
     int *gthr = part_i + p.part_elems;   // per-query shared threshold words, re-initialised every call
+    float *bmax = reinterpret_cast<float *>(gthr + Q);
     hipStream_t st = as_stream(stream);
-    TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
+    TopkPlan pp;
+    static int prepass_on = -1;
+    if (prepass_on < 0) { const char *e = getenv("TSIM_K1_PREPASS"); prepass_on = e ? atoi(e) : 1; }
+    if (prepass_on && plan_prepass(Q, N, p, &pp)) {
+        // threshold pre-pass: block maxima over the first rows, KL-th largest per query -> initial shared bounds
+        const int64_t S = (int64_t)pp.nchunks * pp.rows_per_chunk;
+        int rc0 = k1_launch_blockmax(pp, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, S, bmax, st);
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, pp.P2, Q, p.KL, gthr);
+        TSIM_HIP_CHECK(hipGetLastError());
+    } else {
+        TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
+    }
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));

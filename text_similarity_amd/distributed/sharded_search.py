@@ -51,6 +51,16 @@ class ShardedCorpusSearch:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
 
+    def _all_gather(self, out: torch.Tensor, src: torch.Tensor) -> None:
+        """all_gather_into_tensor; with the gloo backend (CPU rehearsals of the multi-GPU path, e.g. two ranks sharing
+        one GPU) device tensors are staged through host memory, everything else is identical."""
+        if src.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, src.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, src, group=self.group)
+
     def gather_queries(self, q_unit_local: torch.Tensor) -> torch.Tensor:
         """all-gather of equally sized query slices: [Q_local, ld] -> [world*Q_local, ld] (rank-major)."""
         if self.world == 1:
@@ -58,7 +68,7 @@ class ShardedCorpusSearch:
         # bf16 travels as raw bytes so that the gloo test backend (no bf16/int16 support) runs the same code
         src = q_unit_local.contiguous().view(torch.uint8)
         out = torch.empty((self.world * src.shape[0], src.shape[1]), dtype=torch.uint8, device=src.device)
-        dist.all_gather_into_tensor(out, src, group=self.group)
+        self._all_gather(out, src)
         return out.view(torch.bfloat16)
 
     def search(self, q_unit_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -71,7 +81,7 @@ class ShardedCorpusSearch:
         Q = s.shape[0]
         s_cat = torch.empty((self.world * Q, k), dtype=s.dtype, device=s.device)
         i_cat = torch.empty((self.world * Q, k), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(s_cat, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(i_cat, i.contiguous(), group=self.group)
+        self._all_gather(s_cat, s.contiguous())
+        self._all_gather(i_cat, i.contiguous())
         s_all, i_all = s_cat.view(self.world, Q, k), i_cat.view(self.world, Q, k)
         return self.merge([s_all[r] for r in range(self.world)], [i_all[r] for r in range(self.world)], k)

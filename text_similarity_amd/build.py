@@ -16,6 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtsim.so")
 SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_kl32.hip", "encoder.hip"]
+HOT_KERNELS = ("cos_topk_partial", "gemm_bf16", "gemm_xres", "attention_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 
@@ -38,10 +39,37 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = ["hipcc", *FLAGS, *extra_flags, "-c", src, "-o", obj]
+        cmd = ["hipcc", *FLAGS, *extra_flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0 or "warning:" in r.stderr or "error:" in r.stderr:
+            # remarks carry source-context lines; show everything except the remark blocks
+            keep, skip = [], 0
+            for ln in r.stderr.splitlines():
+                if "remark:" in ln:
+                    skip = 2
+                elif skip:
+                    skip -= 1
+                else:
+                    keep.append(ln)
+            print("\n".join(keep), file=sys.stderr, flush=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        # a hot kernel that spills to scratch is a silent 10x slowdown (it happened: nested lambdas that stopped being
+        # inlined put the resident MFMA fragments in memory) -> fail the build instead
+        name = None
+        for ln in r.stderr.splitlines():
+            if "Function Name:" in ln:
+                name = ln.split("Function Name:")[1].split("[")[0].strip()
+            elif "ScratchSize [bytes/lane]:" in ln and name:
+                n = int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
+                if n > 0 and any(k in name for k in HOT_KERNELS):
+                    try:
+                        os.remove(obj)
+                    except OSError:
+                        pass
+                    raise RuntimeError(f"{os.path.basename(src)}: hot kernel {name} uses {n} B/lane of scratch")
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))

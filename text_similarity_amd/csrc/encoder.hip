@@ -100,12 +100,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-fabsf(hx), pe, hx + fabsf(hx));
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NST = 2>
 constexpr int gemm_lds_bytes() {
-    return 2 * (BM + BN) * BK * 2;
+    return NST * (BM + BN) * BK * 2;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+// NST = ring slots.  2: wait vmcnt(0) -> barrier -> issue next -> compute (prefetch distance one k-tile).  > 2: counted
+// vmcnt, prefetch distance NST-1 k-tiles (needs the stage's 1-KiB pieces to split evenly over the waves).
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int NST = 2>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
     const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     constexpr int PIECES = STAGE / 1024, XPIECES = X_BYTES / 1024;
     constexpr int KSTEPS = BK / 16;
     static_assert(TM % 32 == 0 && TN % 32 == 0 && X_BYTES % 1024 == 0 && W_BYTES % 1024 == 0, "tile shape");
+    static_assert(NST == 2 || PIECES % NW == 0, "a deep ring needs equal DMA counts per wave");
+    constexpr int PPW = (PIECES + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -162,12 +166,24 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
     const int nk = K / BK;
-    issue(0, 0);
+    if constexpr (NST == 2) {
+        issue(0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NST - 1; ++i) issue(i < nk ? i : nk - 1, i);   // past-the-end: re-read (uniform vmcnt)
+    }
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // tile kt landed for everyone; everyone finished reading tile kt-1
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char *xs = smem + (kt & 1) * STAGE;
+        if constexpr (NST == 2) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // tile kt landed for everyone; everyone finished reading tile kt-1
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        } else {
+            wait_vmcnt<(NST - 2) * PPW>();  // tile kt landed (NST-2 younger tiles may be in flight)
+            __builtin_amdgcn_s_barrier();
+            const int nx = kt + NST - 1;
+            issue(nx < nk ? nx : nk - 1, nx % NST);
+        }
+        const char *xs = smem + (kt % NST) * STAGE;
         const char *ws = xs + X_BYTES;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
@@ -186,6 +202,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         }
     }
 
+    if constexpr (NST > 2) wait_vmcnt<0>();   // the re-read tiles of the tail must land before LDS is reused / freed
     // ---- epilogue.  acc[i][j][g]: feature n = n0 + wn*TN + i*32 + (g&3) + 8*(g>>2) + 4*h, token m = m0 + wm*TM + j*32 + r
     const int nbase = n0 + wn * TN + 4 * h;
     const int mbase = m0 + wm * TM + r;
@@ -693,11 +710,12 @@ static int mpnet_bucket(int rel, int num_buckets) {
     return ret + large;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int EPI>
+template <int BM, int BN, int BK, int WM, int WN, int EPI, int NST = 2>
 static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
                        const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
-    constexpr int lds = gemm_lds_bytes<BM, BN, BK, WM, WN>();
-    auto kern = gemm_bf16_kernel<BM, BN, BK, WM, WN, EPI>;
+    constexpr int lds = gemm_lds_bytes<BM, BN, BK, WM, WN, NST>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = gemm_bf16_kernel<BM, BN, BK, WM, WN, EPI, NST>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -755,7 +773,13 @@ static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_
 static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
                        const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
     switch (N) {
-        case 384: return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+        case 384: {
+            static int deep = -1;
+            if (deep < 0) { const char *e = getenv("TSIM_LN_DEEP"); deep = e ? atoi(e) : 0; }
+            if (deep)   // BK = 32, 4-slot ring: prefetch distance 3 k-tiles in the same 128 KiB of LDS
+                return launch_gemm<128, 384, 32, 2, 4, EPI_RES_LN, 4>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+            return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+        }
         case 768: return launch_gemm<64, 768, 32, 1, 8, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
         case 64: return launch_gemm<128, 64, 64, 4, 2, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
         default: return fail(TSIM_EUNSUPPORTED, "encoder: hidden size %d has no fused LayerNorm GEMM (64, 384, 768)", N);

@@ -31,7 +31,7 @@ namespace tsim {
 // per query block; nothing proportional to Q*N is ever written.
 // =====================================================================================================
 constexpr int K1_TILE_ROWS = 32;
-constexpr int K1_NSTAGE = 3;
+constexpr int K1_NSTAGE = 3;   // ring slots (tiles); the PAIR variant uses 4 slots = two 2-tile stages
 constexpr int K1_QCAP = 8;  // per-lane candidate queue depth (entries)
 
 template <int KL>
@@ -63,9 +63,9 @@ __device__ __forceinline__ float import_threshold(int key) {
     return key <= K1_GTHR_INIT ? -INFINITY : ordered_to_float(key - 1);
 }
 
-template <int D, int NWAVES, int QW>
+template <int D, int NWAVES, int QW, bool PAIR = false>
 constexpr int k1_lds_bytes() {
-    return K1_NSTAGE * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
+    return (PAIR ? 4 : K1_NSTAGE) * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
 }
 
 // Measured on MI355X (gpurun r01, N = 1 M, d = 384, k = 10; profiles/README.md):
@@ -84,7 +84,8 @@ constexpr int k1_lds_bytes() {
 // MAXONLY = threshold pre-pass: no lists and no queues, every lane just keeps the maximum score of its sub-stream and
 // writes it to part_s[query][partition]; the KL-th largest of a query's block maxima (distinct rows by construction)
 // is a valid lower bound of its final KL-th best score (thr_select_kernel), with which the main pass starts.
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY>
+// PAIR = two tiles per barrier (ring of two 2-tile stages) instead of one tile per barrier (ring of three tiles).
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
@@ -108,9 +109,16 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     // the same time and share them through that XCD's L2.  Speed only; any placement is correct.
     const int b = blockIdx.x;
     const int xcd = b & 7, jj = b >> 3;
-    const int qb = jj % nqb;
-    const int chunk = (jj / nqb) * 8 + xcd;
-    if (chunk >= nchunks) return;
+    int qb, chunk;
+    if (nchunks >= 8) {
+        qb = jj % nqb;
+        chunk = (jj / nqb) * 8 + xcd;
+    } else {   // fewer chunks than XCDs (many query blocks): 8/nchunks XCDs share a chunk and split the query blocks
+        const int per = 8 / nchunks;            // plan_topk makes nchunks 1, 2 or 4; any value < 8 stays correct
+        chunk = xcd < per * nchunks ? xcd % nchunks : nchunks;   // (XCD labels beyond per*nchunks idle)
+        qb = jj * per + xcd / nchunks;
+    }
+    if (chunk >= nchunks || qb >= nqb) return;
 
     const int64_t row0 = (int64_t)chunk * rows_per_chunk;
     const int crows = (int)(((N - row0) < (int64_t)rows_per_chunk) ? (N - row0) : (int64_t)rows_per_chunk);
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     for (int i = 0; i < PPW; ++i)
         src_base[i] = reinterpret_cast<const char *>(ec) + (row0 + src_row[i]) * ROWB + src_off[i];
     const int full_tiles = crows / K1_TILE_ROWS;   // tiles whose 32 rows all exist
-    auto issue_tile = [&](int t, int stage) {
+    auto issue_tile = [&](int t, int stage) __attribute__((always_inline))  {
         const int tt = t < ntiles ? t : ntiles - 1;  // past-the-end tiles re-read the last one: keeps vmcnt uniform
         if (tt < full_tiles) {
             // tiles are contiguous in the corpus: per-lane base pointer + t * STAGE_BYTES
@@ -203,9 +211,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     // (s_waitcnt vmcnt(0)) before every ordinary LDS access that might alias it; the queues never overlap the
     // staging buffers.
     const uint32_t qaddr0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) +
-                            K1_NSTAGE * STAGE_BYTES + wave * (QW * K1_QCAP * 64 * 8) + lane * 8;
+                            (PAIR ? 4 : K1_NSTAGE) * STAGE_BYTES + wave * (QW * K1_QCAP * 64 * 8) + lane * 8;
 
-    auto drain = [&](auto uc) {
+    auto drain = [&](auto uc) __attribute__((always_inline))  {
         constexpr int u = decltype(uc)::value;
         const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
 #pragma unroll 1
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
     for (int u = 0; u < QW; ++u) bmax[u] = -INFINITY;
 
-    auto filter = [&](auto uc, f32x16 &acc, int t) {
+    auto filter = [&](auto uc, f32x16 &acc, int t) __attribute__((always_inline))  {
         constexpr int u = decltype(uc)::value;
         const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
         const int trow = t * K1_TILE_ROWS + 4 * h;  // local (chunk-relative) row of acc[0]
@@ -269,10 +277,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     issue_tile(0, 0);
     issue_tile(1, 1);
 
-    auto do_tile = [&](int t, int stage) {
-        wait_vmcnt<PPW>();                 // my pieces of tile t have landed (tile t+1 may be in flight)
-        __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading tile t-1
-        issue_tile(t + 2, (stage + 2) % K1_NSTAGE);
+    auto compute_tile = [&](int t, int stage) __attribute__((always_inline))  {
         if (!wave_on) return;
         const char *abase = smem + stage * STAGE_BYTES;
         f32x16 acc[QW];
@@ -313,20 +318,47 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         if constexpr (QW > 1) filter(std::integral_constant<int, 1>{}, acc[QW - 1], t);
     };
 
-    int t = 0;
-    for (; t + 3 <= ntiles; t += 3) {
-        do_tile(t, 0);
-        do_tile(t + 1, 1);
-        do_tile(t + 2, 2);
+    if constexpr (PAIR) {
+        // stage = two tiles; stages alternate between slots {0,1} and {2,3}.  At the barrier of pair p everyone has
+        // finished pair p-1, whose slots are exactly those of pair p+1, which is then issued and has one pair-time
+        // (~48 MFMAs per wave) to land.
+        auto do_pair = [&](int t, int slot) __attribute__((always_inline))  {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            issue_tile(t + 2, (slot + 2) & 3);
+            issue_tile(t + 3, (slot + 3) & 3);
+            compute_tile(t, slot);
+            if (t + 1 < ntiles) compute_tile(t + 1, slot + 1);
+        };
+        int t = 0;
+        for (; t + 4 <= ntiles; t += 4) {
+            do_pair(t, 0);
+            do_pair(t + 2, 2);
+        }
+        if (t < ntiles) do_pair(t, 0);
+        if (t + 2 < ntiles) do_pair(t + 2, 2);
+    } else {
+        auto do_tile = [&](int t, int stage) __attribute__((always_inline))  {
+            wait_vmcnt<PPW>();                 // my pieces of tile t have landed (tile t+1 may be in flight)
+            __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading tile t-1
+            issue_tile(t + 2, (stage + 2) % K1_NSTAGE);
+            compute_tile(t, stage);
+        };
+        int t = 0;
+        for (; t + 3 <= ntiles; t += 3) {
+            do_tile(t, 0);
+            do_tile(t + 1, 1);
+            do_tile(t + 2, 2);
+        }
+        if (t < ntiles) do_tile(t, 0);
+        if (t + 1 < ntiles) do_tile(t + 1, 1);
     }
-    if (t < ntiles) do_tile(t, 0);
-    if (t + 1 < ntiles) do_tile(t + 1, 1);
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
 
     if (wave_on) {
         const int P2 = nchunks * 2;
         const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
-        auto flush = [&](auto uc) {
+        auto flush = [&](auto uc) __attribute__((always_inline))  {
             constexpr int u = decltype(uc)::value;
             if constexpr (MAXONLY) {
                 if (q0 + 32 * u + r < Q) part_s[(int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h] = bmax[u];
@@ -388,6 +420,12 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     int64_t max_ch = (N + 255) / 256;  // at least 256 rows per chunk
     if (nch > max_ch) nch = max_ch;
     if (nch < 1) nch = 1;
+    if (nch < 8) {   // power of two, so that whole XCDs can share a chunk (see the block mapping in the kernel)
+        int p2 = 1;
+        while (p2 < nch) p2 *= 2;
+        nch = p2 <= max_ch ? p2 : (p2 / 2 >= 1 ? p2 / 2 : 1);
+        if (nch > 4 && nch < 8) nch = 4;
+    }
     int64_t rpc = (N + nch - 1) / nch;
     rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;
     p->rows_per_chunk = (int)rpc;
@@ -397,18 +435,20 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false>
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false>
 static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st) {
-    constexpr int lds = k1_lds_bytes<D, NWAVES, QW>();
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY>;
+    constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    const int grid = ((p.nchunks + 7) / 8) * 8 * p.nqb;
+    const int grid = p.nchunks >= 8 ? ((p.nchunks + 7) / 8) * 8 * p.nqb
+                                    : 8 * ((p.nqb + (8 / p.nchunks) - 1) / (8 / p.nchunks));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, eq, (int)Q, ec, N, p.rows_per_chunk,
                        p.nchunks, p.nqb, gthr, part_s, part_i);
     TSIM_HIP_CHECK(hipGetLastError());
@@ -421,7 +461,13 @@ static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, c
     switch (D) {
         case 128: return launch_k1<128, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 256: return launch_k1<256, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 384: return launch_k1<384, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 384: {
+            static int pair = -1;
+            if (pair < 0) { const char *e = getenv("TSIM_K1_PAIR"); pair = e ? atoi(e) : 1; }
+            if (pair && !MAXONLY && KL == 16)
+                return launch_k1<384, 8, 1, KL, MAXONLY, true>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+            return launch_k1<384, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        }
         case 512: return launch_k1<512, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         case 768: return launch_k1<768, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);

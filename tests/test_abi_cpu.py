@@ -102,3 +102,20 @@ def test_synthetic_generators_are_deterministic():
     assert presets.to_bf16_bits(np.array([1.0, -2.0], np.float32)).tolist() == [0x3F80, 0xC000]
     w = presets.synthetic_weights("tiny-mpnet")
     assert "encoder.relative_attention_bias.weight" in w and "embeddings.token_type_embeddings.weight" not in w
+
+
+def test_hf_directory_round_trip_and_config_validation(tmp_path):
+    from text_similarity_amd import presets
+    from text_similarity_amd.weights import config_from_hf, load_hf_dir, save_hf_dir
+    cfg = presets.PRESETS["tiny-bert"]
+    w = presets.synthetic_weights("tiny-bert")
+    save_hf_dir(str(tmp_path), cfg, w)
+    cfg2, w2 = load_hf_dir(str(tmp_path))
+    assert cfg2 == cfg and all(np.array_equal(w[k], w2[k]) for k in w)
+    with pytest.raises(ValueError):
+        config_from_hf({"model_type": "gpt2"})
+    with pytest.raises(ValueError):
+        config_from_hf({"model_type": "bert", "hidden_act": "relu", "num_hidden_layers": 1, "hidden_size": 64,
+                        "num_attention_heads": 4, "intermediate_size": 128, "vocab_size": 10, "max_position_embeddings": 8})
+    with pytest.raises(FileNotFoundError):
+        load_hf_dir(str(tmp_path / "nope"))

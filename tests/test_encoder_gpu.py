@@ -152,3 +152,49 @@ def test_e2e_config1_encode_text_and_mining_pipeline():
     rv, ri = search_ref.mining_search(e[:100], e, 10, chunk=400)
     np.testing.assert_array_equal(got, ri)
     np.testing.assert_array_equal(pipe.last_scores.cpu().numpy(), rv)
+
+
+@pytest.mark.parametrize("preset", ["all-MiniLM-L6-v2", "all-mpnet-base-v2"])
+def test_long_sequences_online_softmax_and_bias_buckets(preset):
+    """Sequences of 1..max length (256 / 384 tokens): many key blocks per query block, so the online-softmax rescale and
+    MPNet's log-spaced relative-position buckets (|distance| up to 383) are exercised; one sequence has a single huge
+    score spike late in the sequence (a key identical to the query token far away), which forces a max jump at a late tile."""
+    cfg = presets.PRESETS[preset]
+    w = presets.synthetic_weights(preset)
+    maxlen = 256 if cfg.arch == "bert" else 384
+    lens = [1, 2, 31, 32, 33, 64, 65, 100, maxlen - 1, maxlen]
+    ids = presets.randint(preset + "/long", sum(lens), 5, cfg.vocab).astype(np.int32)
+    cu = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=cu[1:])
+    ids[cu[-2] + 3] = ids[cu[-1] - 2]          # repeated token far apart in the longest sequence
+    enc = NativeEncoder.from_preset(preset, max_tokens=int(cu[-1]), max_seqs=len(lens))
+    r = enc.forward_packed(torch.from_numpy(ids).to(DEV), torch.from_numpy(cu.astype(np.int32)).to(DEV), pooled=True)
+    torch.cuda.synchronize()
+    p = r["pooled"].cpu().numpy()
+    ref = encoder_ref.encode_packed(cfg, w, ids, cu, batch_size=4)
+    err = np.abs(p - ref).max()
+    cos = _cos_rows(p, ref).min()
+    print(f"{preset} long: max|err|={err:.4f} min cos={cos:.6f}")
+    assert err <= POOL_TOL and cos >= COS_MIN
+
+
+def test_from_pretrained_local_directory(tmp_path):
+    """sentence_encoder.py:187-217: weights come from a local HF directory (config.json + model.safetensors)."""
+    from text_similarity_amd.configurations.config import Configuration, ModelParameters
+    from text_similarity_amd.models.sentence_encoder import OnnxSentenceTransformerWrapper, SentenceTransformerWrapper
+    from text_similarity_amd.weights import load_hf_dir, save_hf_dir
+    preset = "tiny-mpnet"
+    cfg = presets.PRESETS[preset]
+    w = presets.synthetic_weights(preset)
+    save_hf_dir(str(tmp_path), cfg, w)
+    cfg2, w2 = load_hf_dir(str(tmp_path))
+    assert cfg2 == cfg and set(w2) == set(w) and all(np.array_equal(w[k], w2[k]) for k in w)
+    params = Configuration(model_parameters=ModelParameters(preset, hidden_size=64), model=preset, save_path="",
+                           device=torch.device(DEV), max_tokens_per_batch=512, max_seqs_per_batch=32)
+    g = golden(f"encoder_{preset}.npz")
+    ids, mask = torch.from_numpy(g["input_ids"]).to(DEV), torch.from_numpy(g["attention_mask"]).to(DEV)
+    for cls in (OnnxSentenceTransformerWrapper, SentenceTransformerWrapper):
+        m = cls.from_pretrained(str(tmp_path), params=params)
+        from text_similarity_amd.dataset.dataset import EmbeddingsFeatures
+        out = m.encode(EmbeddingsFeatures(ids, mask))
+        assert np.abs(out.cpu().numpy() - g["pooled"]).max() <= POOL_TOL

@@ -15,7 +15,10 @@ from typing import Dict, List, Optional, Union
 
 import torch
 
+import os
+
 from .. import ops
+from ..index import GpuFlatIndex
 
 
 class Pipeline:
@@ -104,3 +107,63 @@ class SentenceMiningPipeline(SearchPipeline):
 
     def __call__(self, queries, max_num_results: int, return_embeddings: bool = False):
         return self._search(queries, None, max_num_results, return_embeddings)
+
+
+class SemanticSearchPipeline(SearchPipeline):
+    """/root/reference/src/pipeline/search_pipeline.py:96-175 with the hnswlib ANN index replaced by an exact index in
+    HBM (:class:`text_similarity_amd.index.GpuFlatIndex`): same constructor (``index_path`` first), ``_index``,
+    ``_search`` / ``__call__`` returning ``{query_idx: [texts best-first]}``, ``add_to_index``, ``remove_from_index``,
+    ``num_indexed``.  Differences: results are exact; ``ef`` / ``ef_construction`` / ``M`` are accepted and unused (the
+    reference's ``assert max_num_results < ef`` has no meaning here); ``add_to_index`` also appends the texts to
+    ``self.corpus`` — the reference only grows the index, so its new ids cannot be mapped back to text."""
+
+    def __init__(self, index_path, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.index_path = index_path
+        hidden = getattr(self.params.model_parameters, "hidden_size", None) or self.model.get_sentence_embedding_dimension()
+        self.index = GpuFlatIndex(space="cosine", dim=hidden, device=self.params.device)
+        if os.path.exists(os.path.join(self.index_path, "index.bin")):
+            self.index.load_index(self.index_path)
+        else:
+            self._index(self.corpus)
+
+    def _index(self, corpus):
+        os.makedirs(self.index_path, exist_ok=True)
+        corpus_embeddings = self.encode_corpus(corpus)
+        self.index.init_index(max_elements=len(corpus), ef_construction=getattr(self.params, "ef_construction", 0),
+                              M=getattr(self.params, "M", 0))
+        self.index.add_items(corpus_embeddings, list(range(corpus_embeddings.shape[0])))
+        self.index.save_index(self.index_path)
+        self.index.set_ef(getattr(self.params, "ef", 0))
+
+    def _search(self, queries, max_num_results: int):
+        query_embeddings = self.encode_corpus(queries)
+        labels, scores = self.index.search(query_embeddings, max_num_results)
+        self.last_labels, self.last_scores = labels, scores
+        top_results = {}
+        for qidx, row in enumerate(labels.cpu().tolist()):
+            top_results[qidx] = [self.corpus[i] for i in row if i >= 0]
+        return top_results
+
+    def __call__(self, queries, max_num_results: int):
+        return self._search(queries, max_num_results)
+
+    def add_to_index(self, text):
+        if isinstance(text, str):
+            text = [text]
+        embeddings = self.encode_corpus(list(text))
+        first = len(self.corpus)
+        self.index.resize_index(self.index.get_current_count() + embeddings.shape[0])
+        self.index.add_items(embeddings, list(range(first, first + embeddings.shape[0])))
+        self.corpus = list(self.corpus) + list(text)
+
+    def remove_from_index(self, ids):
+        for id in ids:
+            try:
+                self.index.mark_deleted(id)
+            except RuntimeError:
+                continue      # can't find id, continue (search_pipeline.py:167-169)
+
+    def num_indexed(self):
+        """current number of indexed embeddings"""
+        return self.index.num_live()

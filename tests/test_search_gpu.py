@@ -20,17 +20,25 @@ def _unit_dev(x_f32_unit_bf16exact: np.ndarray, d: int):
     return t.to(DEV)
 
 
-def _check_exact(q, c, k, idx_offset=0):
+def _check_exact(q, c, k, idx_offset=0, oracle_queries=None):
+    """GPU top-k vs the oracle, bit for bit.  For big shapes the O(Q*N*d) oracle runs on a sample of the queries
+    (``oracle_queries``); every query still gets the checks that need no full oracle: returned scores are the canonical
+    scores of the returned (query, row) pairs, lists are ordered by (score desc, index asc), indices are distinct."""
     d = q.shape[1]
     s, i = ops.cosine_topk(_unit_dev(q, d), _unit_dev(c, d), d, k, idx_offset)
     torch.cuda.synchronize()
-    rs, ri = search_ref.cosine_topk(q, c, k, idx_offset)
-    kk = rs.shape[1]
-    np.testing.assert_array_equal(i.cpu().numpy()[:, :kk], ri)
-    np.testing.assert_array_equal(s.cpu().numpy()[:, :kk], rs)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    kk = min(k, c.shape[0])
+    sel = np.arange(q.shape[0]) if oracle_queries is None else np.asarray(oracle_queries)
+    rs, ri = search_ref.cosine_topk(q[sel], c, k, idx_offset)
+    np.testing.assert_array_equal(i[sel][:, :kk], ri)
+    np.testing.assert_array_equal(s[sel][:, :kk], rs)
     if kk < k:  # corpus smaller than k: padded with -1 / -inf
-        assert (i.cpu().numpy()[:, kk:] == -1).all()
-        assert np.isneginf(s.cpu().numpy()[:, kk:]).all()
+        assert (i[:, kk:] == -1).all() and np.isneginf(s[:, kk:]).all()
+    qi = np.repeat(np.arange(q.shape[0]), kk)
+    pair = search_ref.canonical_scores_pairs(q, c, qi, (i[:, :kk] - idx_offset).reshape(-1)).reshape(-1, kk)
+    np.testing.assert_array_equal(s[:, :kk], pair)
+    assert ((s[:, :-1] > s[:, 1:]) | ((s[:, :-1] == s[:, 1:]) & (i[:, :-1] < i[:, 1:])))[:, :kk - 1].all()
 
 
 def test_golden_topk_fixture_with_duplicates():
@@ -50,11 +58,45 @@ def test_golden_topk_fixture_with_duplicates():
     (5, 40, 384, 12),         # tiny corpus
     (9, 2000, 256, 20),       # KL = 32 lists
     (64, 33000, 384, 1),
+    (1, 1000, 384, 10),       # a single query
+    (40, 3001, 512, 10),      # d = 512 (4-wave kernel)
+    (12, 5000, 384, 28),      # largest supported k (KL = 32)
+    (300, 262144 + 77, 384, 10),   # just above the pre-pass threshold, ragged tail, 2 query blocks
+    (2600, 300000, 384, 10),  # 11 query blocks -> fewer than 8 corpus chunks (XCD-sharing block map)
 ])
 def test_random_exact(Q, N, d, k):
-    q = presets.synthetic_embeddings(Q, d, f"tq/{Q}/{N}/{d}")
-    c = presets.synthetic_embeddings(N, d, f"tc/{Q}/{N}/{d}")
-    _check_exact(q, c, k, idx_offset=123456789012)
+    big = Q * N > 4_000_000          # keep the CPU side (generator + oracle) to a few seconds per case
+    if big:                          # data drawn on the GPU, unit rows downloaded for the sampled oracle
+        g = torch.Generator(device=DEV).manual_seed(Q * 7919 + N)
+        cu = ops.l2norm_rows(torch.randn((N, d), generator=g, device=DEV))
+        qu = ops.l2norm_rows(torch.randn((Q, d), generator=g, device=DEV))
+        c, q = cu[:, :d].float().cpu().numpy(), qu[:, :d].float().cpu().numpy()
+        sample = sorted(set([0, Q // 3, Q // 2, Q - 1]))
+    else:
+        q = presets.synthetic_embeddings(Q, d, f"tq/{Q}/{N}/{d}")
+        c = presets.synthetic_embeddings(N, d, f"tc/{Q}/{N}/{d}")
+        sample = None
+    _check_exact(q, c, k, idx_offset=123456789012, oracle_queries=sample)
+
+
+def test_prepass_threshold_is_safe_when_best_rows_sit_in_the_sample():
+    """The pre-pass seeds thresholds from the first rows.  Put every query's true neighbours INSIDE that sample (so the
+    seeded bound is as tight as it can be) and duplicates of them at the far end of the corpus: ties must still resolve
+    to the lower index and nothing may be dropped."""
+    N, d = 400_000, 384
+    g = torch.Generator(device=DEV).manual_seed(7)
+    c = torch.randn((N, d), generator=g, device=DEV)
+    q = c[:64].clone() + 0.01 * torch.randn((64, d), generator=g, device=DEV)   # neighbours = rows 0..63 (in the sample)
+    c[N - 64:] = c[:64]                                                          # exact duplicates at the end
+    cu, qu = ops.l2norm_rows(c), ops.l2norm_rows(q)
+    s, i = ops.cosine_topk(qu, cu, d, 10)
+    torch.cuda.synchronize()
+    i = i.cpu().numpy()
+    assert (i[:, 0] == np.arange(64)).all() and (i[:, 1] == N - 64 + np.arange(64)).all()
+    assert torch.equal(s[:, 0], s[:, 1])
+    rs, ri = search_ref.cosine_topk(qu[:8, :d].float().cpu().numpy(), cu[:, :d].float().cpu().numpy(), 10)
+    np.testing.assert_array_equal(i[:8], ri)
+    np.testing.assert_array_equal(s[:8].cpu().numpy(), rs)
 
 
 def test_corpus_smaller_than_k():

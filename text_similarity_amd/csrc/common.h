@@ -87,6 +87,23 @@ __device__ __forceinline__ bf16_t f64_to_bf16(double v) {
 }
 __device__ __forceinline__ bf16_t canonical_unit_elem(float x, double inv) { return f64_to_bf16((double)x * inv); }
 
+__device__ __forceinline__ float gelu_erf(float x) {
+    // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output resolution),
+    // raw v_rcp_f32 / v_exp_f32 (1 ulp) with the constants folded: 14 VALU instructions (erff(): ~30; the same formula
+    // with an IEEE-correct reciprocal and a guarded exp: 29).  FFN1's epilogue is VALU-bound, so this matters.
+    //   1 - erf(|x|/sqrt2) = poly(t) * t * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)
+    //   gelu = hx + |hx| (1 - pe) with hx = x/2
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    const float pe = poly * t * e;
+    const float hx = 0.5f * x;
+    return fmaf(-fabsf(hx), pe, hx + fabsf(hx));
+}
+
 // async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,

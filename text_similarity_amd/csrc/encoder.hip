@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_pp.h"
 
 namespace tsim {
 
@@ -82,23 +83,6 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 // HBM/MFMA balance point, so operand reuse through L2 (XCD-aware tile order) matters.
 // =====================================================================================================
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2 };
-
-__device__ __forceinline__ float gelu_erf(float x) {
-    // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output resolution),
-    // raw v_rcp_f32 / v_exp_f32 (1 ulp) with the constants folded: 14 VALU instructions (erff(): ~30; the same formula
-    // with an IEEE-correct reciprocal and a guarded exp: 29).  FFN1's epilogue is VALU-bound, so this matters.
-    //   1 - erf(|x|/sqrt2) = poly(t) * t * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)
-    //   gelu = hx + |hx| (1 - pe) with hx = x/2
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    const float pe = poly * t * e;
-    const float hx = 0.5f * x;
-    return fmaf(-fabsf(hx), pe, hx + fabsf(hx));
-}
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NST = 2>
 constexpr int gemm_lds_bytes() {
@@ -769,6 +753,7 @@ struct tsim_encoder {
     std::vector<void *> allocs;
     // activations
     bf16_t *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *ctx = nullptr, *h1 = nullptr;
+    float *ybuf = nullptr;   // fp32 pre-LayerNorm sums (wide models only)
 };
 
 namespace tsim {
@@ -873,13 +858,26 @@ static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_
     static int use_xres = -1;
     if (use_xres < 0) { const char *e = getenv("TSIM_GEMM_XRES"); use_xres = e ? atoi(e) : 1; }
     if (use_xres && K == 384 && N % XR_BN == 0) return gemm_xres<EPI>(X, W, bias, out, M, N, st);
+    static int big = -1;
+    if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
+    if (big && K >= 768 && gemm_pp_supported(N, K))
+        return gemm_pp(EPI == EPI_GELU ? PP_EPI_GELU : PP_EPI_BIAS, X, W, bias, out, M, N, K, st);
     if (N % 128 == 0)
         return launch_gemm<128, 128, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
     return launch_gemm<128, 64, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
 }
 
 static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
-                       const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
+                       const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf, hipStream_t st) {
+    static int big = -1;
+    if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
+    if (big && ybuf && N >= 512 && gemm_pp_supported(N, K)) {
+        // wide rows: a workgroup cannot own whole 768-feature rows at a 256-token tile, so the projection writes
+        // fp32 sums and a row kernel adds the residual and normalises (HBM-bound, 8 B per element)
+        int rc = gemm_pp(PP_EPI_F32, X, W, bias, ybuf, M, N, K, st);
+        if (rc) return rc;
+        return res_ln_rows(ybuf, res, gamma, beta, eps, out, M, N, st);
+    }
     switch (N) {
         case 384: {
             // 128-token tiles, one workgroup per CU: mt tiles take ceil(mt/256) rounds and a nearly empty last round
@@ -968,6 +966,10 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
         if ((rc = dev_alloc(e, a.n * 2, (void **)a.p))) return bail(rc);
         if (hipMemset(*a.p, 0, a.n * 2) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
     }
+    if (H >= 512 && gemm_pp_supported(H, H)) {
+        if ((rc = dev_alloc(e, Tp * H * 4, (void **)&e->ybuf))) return bail(rc);
+        if (hipMemset(e->ybuf, 0, Tp * H * 4) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
+    }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(TSIM_EHIP, "sync after upload failed"));
     *out = e;
     return TSIM_OK;
@@ -1019,9 +1021,9 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
             if (dh == 16) ATT(16); else if (dh == 32) ATT(32); else ATT(64);
 #undef ATT
             TSIM_HIP_CHECK(hipGetLastError());
-            if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, st))) return rc;
+            if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
             if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

@@ -102,6 +102,23 @@ int tsim_mean_pool(const void *hidden, int hidden_dtype, const int32_t *mask, in
  */
 typedef struct tsim_encoder tsim_encoder;
 
+/* Projection operand formats.  TSIM_W_MXFP8: weights AND the activations entering each projection are OCP MXFP8
+ * (e4m3 elements, one E8M0 power-of-two scale per 32 consecutive elements of the contraction axis), multiplied by
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate); needs hidden % 256 == 0 and ffn % 256 == 0.
+ * The reference has no fp8 path (HF fp32 forward, src/models/sentence_encoder.py:33): this is north_star's config 5. */
+#define TSIM_W_BF16 0
+#define TSIM_W_MXFP8 1
+
+/* bf16 [rows, K] (device) -> MXFP8: q_out uint8 [rows, K] e4m3 bytes, scale_out uint8 [rows, K/32] E8M0 bytes.
+ * K % 32 == 0.  Bit-exact restatement: oracle/fp8_ref.mx_quantize. */
+int tsim_quantize_mxfp8(const void *x_bf16, int64_t rows, int K, void *q_out, void *scale_out, void *stream);
+
+/* out_f32 [M, N] = dequant(xq, xs) [M, K] @ dequant(wq, ws) [N, K]^T + bias  on the block-scaled fp8 MFMA (the projection
+ * kernel of the MXFP8 encoder, exposed for parity tests).  N % 256 == 0, K % 128 == 0, K >= 256; xq, xs and out_f32 must be
+ * allocated for M rounded up to a multiple of 256 rows (the kernel works on whole 256-row tiles). */
+int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, const void *ws, const float *bias, float *out_f32,
+                    int M, int N, int K, void *stream);
+
 typedef struct tsim_encoder_config {
     int32_t arch;          /* TSIM_ARCH_BERT | TSIM_ARCH_MPNET */
     int32_t num_layers, hidden, heads, ffn, vocab, max_pos;
@@ -110,6 +127,7 @@ typedef struct tsim_encoder_config {
     float ln_eps;
     int32_t max_tokens;    /* capacity of the activation workspace, in packed tokens per call */
     int32_t max_seqs;      /* capacity in sequences per call */
+    int32_t weight_dtype;  /* TSIM_W_BF16 | TSIM_W_MXFP8 (projection operands; BASELINE.json configs[4]) */
 } tsim_encoder_config;
 
 /* Per-layer weights, all HOST pointers to float32 in torch nn.Linear layout [out, in]; the engine

@@ -59,8 +59,9 @@ def mpnet_relative_bucket(rel: torch.Tensor, num_buckets: int = 32, max_distance
     return ret + torch.where(is_small, n, large)
 
 
-def encoder_forward(cfg, w: Dict[str, np.ndarray], input_ids, attention_mask) -> torch.Tensor:
-    """last_hidden_state [B,S,H] float32 for padded ``input_ids``/``attention_mask`` [B,S]."""
+def encoder_forward(cfg, w: Dict[str, np.ndarray], input_ids, attention_mask, linear=F.linear) -> torch.Tensor:
+    """last_hidden_state [B,S,H] float32 for padded ``input_ids``/``attention_mask`` [B,S].  ``linear`` replaces
+    F.linear in the six projections of a layer (oracle.fp8_ref.mx_linear for the fp8 variant)."""
     ids = torch.as_tensor(np.asarray(input_ids)).long()
     mask = torch.as_tensor(np.asarray(attention_mask)).long()
     B, S = ids.shape
@@ -91,7 +92,7 @@ def encoder_forward(cfg, w: Dict[str, np.ndarray], input_ids, attention_mask) ->
             nq, nk, nv, no = (p + "attention.attn.q", p + "attention.attn.k",
                               p + "attention.attn.v", p + "attention.attn.o")
             ln1 = p + "attention.LayerNorm"
-        lin = lambda t, n: F.linear(t, _t(w, n + ".weight"), _t(w, n + ".bias"))
+        lin = lambda t, n: linear(t, _t(w, n + ".weight"), _t(w, n + ".bias"))
         q = lin(x, nq).view(B, S, nh, dh).transpose(1, 2)
         k = lin(x, nk).view(B, S, nh, dh).transpose(1, 2)
         v = lin(x, nv).view(B, S, nh, dh).transpose(1, 2)
@@ -116,10 +117,10 @@ def mean_pool(hidden, attention_mask) -> torch.Tensor:
     return (hidden * m).sum(1) / torch.clamp(m.sum(1), min=1e-9)
 
 
-def encode(cfg, w, input_ids, attention_mask) -> torch.Tensor:
+def encode(cfg, w, input_ids, attention_mask, linear=F.linear) -> torch.Tensor:
     """OnnxSentenceTransformerWrapper.forward (sentence_encoder.py:32-39) with Identity projection."""
     with torch.no_grad():
-        return mean_pool(encoder_forward(cfg, w, input_ids, attention_mask), attention_mask)
+        return mean_pool(encoder_forward(cfg, w, input_ids, attention_mask, linear=linear), attention_mask)
 
 
 def pad_batch(flat_ids: np.ndarray, cu: np.ndarray, rows, pad_id: int = 0):
@@ -135,7 +136,7 @@ def pad_batch(flat_ids: np.ndarray, cu: np.ndarray, rows, pad_id: int = 0):
     return ids, mask
 
 
-def encode_packed(cfg, w, flat_ids, cu, batch_size: int = 16) -> np.ndarray:
+def encode_packed(cfg, w, flat_ids, cu, batch_size: int = 16, linear=F.linear) -> np.ndarray:
     """The reference's encode_text loop (sentence_encoder.py:136-173) on pre-tokenised input:
     sort by length, batches of ``batch_size`` padded to the longest, un-sort.  float32 [n,H]."""
     n = len(cu) - 1
@@ -145,5 +146,5 @@ def encode_packed(cfg, w, flat_ids, cu, batch_size: int = 16) -> np.ndarray:
     for s in range(0, n, batch_size):
         rows = order[s:s + batch_size]
         ids, mask = pad_batch(flat_ids, cu, rows, cfg.pad_id)
-        out[rows] = encode(cfg, w, ids, mask).numpy()
+        out[rows] = encode(cfg, w, ids, mask, linear=linear).numpy()
     return out

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libtsim.so")
 
 TSIM_F32, TSIM_BF16 = 0, 1
 ARCH_BERT, ARCH_MPNET = 0, 1
+W_BF16, W_MXFP8 = 0, 1
 
 
 class TsimError(RuntimeError):
@@ -21,7 +22,7 @@ class EncoderConfigC(C.Structure):
     _fields_ = [("arch", C.c_int32), ("num_layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
                 ("ffn", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32), ("pad_id", C.c_int32),
                 ("rel_buckets", C.c_int32), ("ln_eps", C.c_float), ("max_tokens", C.c_int32),
-                ("max_seqs", C.c_int32)]
+                ("max_seqs", C.c_int32), ("weight_dtype", C.c_int32)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -54,6 +55,9 @@ _SIGS = {
     "tsim_cos_sim": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "tsim_mean_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),
+    "tsim_quantize_mxfp8": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsim_gemm_mxfp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
     "tsim_encoder_create": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC),
                                       C.POINTER(C.c_void_p)]),
     "tsim_encoder_destroy": (None, [C.c_void_p]),

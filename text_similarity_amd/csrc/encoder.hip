@@ -12,6 +12,7 @@
 // Weights bf16 in nn.Linear layout [out, in] (K contiguous for both GEMM operands); embedding tables,
 // biases and LayerNorm parameters float32.
 #include <math.h>
+#include <cmath>
 
 #include <stdlib.h>
 #include <string.h>
@@ -747,6 +748,8 @@ struct tsim_encoder {
     int relw = 0;
     struct Layer {
         bf16_t *wqkv, *wo, *w1, *w2;
+        uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes ...
+        uint8_t *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // ... and E8M0 block scales [out, in/32]
         float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
     };
     std::vector<Layer> layers;
@@ -754,6 +757,7 @@ struct tsim_encoder {
     // activations
     bf16_t *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *ctx = nullptr, *h1 = nullptr;
     float *ybuf = nullptr;   // fp32 pre-LayerNorm sums (wide models only)
+    uint8_t *aq = nullptr, *as = nullptr, *hq = nullptr, *hs = nullptr;   // MXFP8 images of a projection's input ([Tp,H] / [Tp,F])
 };
 
 namespace tsim {
@@ -786,6 +790,56 @@ static int upload_bf16(tsim_encoder *e, const std::vector<const float *> &parts,
 
 // MPNet relative_position_bucket (transformers mpnet/modeling_mpnet.py relative_position_bucket):
 // rel = key_col - query_col, n = -rel.
+// fp32 -> e4m3 byte, nearest even, |v| <= 448 (oracle/fp8_ref.f32_to_e4m3)
+static uint8_t host_f32_to_e4m3(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0;
+    const double a = std::fabs((double)v);
+    if (a == 0.0) return sign;
+    int exp;
+    const double mant = std::frexp(a, &exp);          // a = mant * 2^exp, mant in [0.5, 1)
+    long byte;
+    if (a >= std::ldexp(1.0, -6))
+        byte = ((long)(exp - 1 + 7) << 3) + std::lrint((mant * 2.0 - 1.0) * 8.0);   // a carry of 8 bumps the exponent
+    else
+        byte = std::lrint(std::ldexp(a, 9));
+    if (byte > 0x7e) byte = 0x7e;
+    return (uint8_t)byte | sign;
+}
+
+// parts: row blocks of n_rows x K fp32 (nn.Linear [out, in]) -> MXFP8 along K (oracle/fp8_ref.mx_quantize)
+static int upload_mxfp8(tsim_encoder *e, const std::vector<const float *> &parts, size_t n_rows, size_t K, uint8_t **q,
+                        uint8_t **sc) {
+    const size_t rows = n_rows * parts.size(), nb = K / 32;
+    std::vector<uint8_t> hq(rows * K), hs(rows * nb);
+    for (size_t p = 0; p < parts.size(); ++p)
+        for (size_t r = 0; r < n_rows; ++r)
+            for (size_t b = 0; b < nb; ++b) {
+                const float *src = parts[p] + r * K + b * 32;
+                float amax = 0.f;
+                for (int i = 0; i < 32; ++i) amax = std::fmax(amax, std::fabs(src[i]));
+                int sexp = 0;
+                if (amax > 0.f) {
+                    int ex;
+                    (void)std::frexp((double)amax, &ex);
+                    sexp = ex - 1 - 8;
+                    sexp = sexp < -127 ? -127 : (sexp > 127 ? 127 : sexp);
+                }
+                uint8_t *dst = hq.data() + (p * n_rows + r) * K + b * 32;
+                for (int i = 0; i < 32; ++i) {
+                    double y = std::ldexp((double)src[i], -sexp);
+                    y = y > 448.0 ? 448.0 : (y < -448.0 ? -448.0 : y);
+                    dst[i] = host_f32_to_e4m3((float)y);
+                }
+                hs[(p * n_rows + r) * nb + b] = (uint8_t)(sexp + 127);
+            }
+    int rc = dev_alloc(e, hq.size(), (void **)q);
+    if (rc) return rc;
+    if ((rc = dev_alloc(e, hs.size(), (void **)sc))) return rc;
+    TSIM_HIP_CHECK(hipMemcpy(*q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+    TSIM_HIP_CHECK(hipMemcpy(*sc, hs.data(), hs.size(), hipMemcpyHostToDevice));
+    return TSIM_OK;
+}
+
 static int mpnet_bucket(int rel, int num_buckets) {
     int ret = 0;
     int n = -rel;
@@ -915,6 +969,10 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
     TSIM_REQUIRE(cfg->arch == TSIM_ARCH_BERT || cfg->arch == TSIM_ARCH_MPNET, "encoder_create: unknown arch");
     TSIM_REQUIRE(w->word_emb && w->pos_emb && w->emb_ln_g && w->emb_ln_b && w->layers, "encoder_create: missing weights");
     TSIM_REQUIRE(cfg->arch != TSIM_ARCH_MPNET || w->rel_bias, "encoder_create: MPNet needs rel_bias");
+    const bool mx = cfg->weight_dtype == TSIM_W_MXFP8;
+    TSIM_REQUIRE(cfg->weight_dtype == TSIM_W_BF16 || mx, "encoder_create: unknown weight_dtype %d", cfg->weight_dtype);
+    if (mx && !(gemm_pp_mx_supported(H, H) && gemm_pp_mx_supported(3 * H, H) && gemm_pp_mx_supported(F, H) && gemm_pp_mx_supported(H, F)))
+        return fail(TSIM_EUNSUPPORTED, "encoder_create: MXFP8 projections need hidden and ffn to be multiples of 256 (got %d, %d)", H, F);
     tsim_encoder *e = new tsim_encoder();
     e->cfg = *cfg;
     e->Tp = (cfg->max_tokens + 127) / 128 * 128 + 128;
@@ -946,6 +1004,12 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
         if ((rc = upload_bf16(e, {lw.wo}, (size_t)H * H, &d.wo))) return bail(rc);
         if ((rc = upload_bf16(e, {lw.w1}, (size_t)F * H, &d.w1))) return bail(rc);
         if ((rc = upload_bf16(e, {lw.w2}, (size_t)H * F, &d.w2))) return bail(rc);
+        if (mx) {
+            if ((rc = upload_mxfp8(e, {lw.wq, lw.wk, lw.wv}, H, H, &d.qqkv, &d.sqkv))) return bail(rc);
+            if ((rc = upload_mxfp8(e, {lw.wo}, H, H, &d.qo, &d.so))) return bail(rc);
+            if ((rc = upload_mxfp8(e, {lw.w1}, F, H, &d.q1, &d.s1))) return bail(rc);
+            if ((rc = upload_mxfp8(e, {lw.w2}, H, F, &d.q2, &d.s2))) return bail(rc);
+        }
         std::vector<float> bq(3 * (size_t)H);
         memcpy(bq.data(), lw.bq, H * 4);
         memcpy(bq.data() + H, lw.bk, H * 4);
@@ -970,9 +1034,32 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
         if ((rc = dev_alloc(e, Tp * H * 4, (void **)&e->ybuf))) return bail(rc);
         if (hipMemset(e->ybuf, 0, Tp * H * 4) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
     }
+    if (mx) {
+        struct { uint8_t **p; size_t n; } qb[] = {{&e->aq, Tp * H}, {&e->as, Tp * H / 32}, {&e->hq, Tp * F}, {&e->hs, Tp * F / 32}};
+        for (auto &a : qb) {
+            if ((rc = dev_alloc(e, a.n, (void **)a.p))) return bail(rc);
+            if (hipMemset(*a.p, 0, a.n) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
+        }
+    }
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(TSIM_EHIP, "sync after upload failed"));
     *out = e;
     return TSIM_OK;
+}
+
+extern "C" int tsim_quantize_mxfp8(const void *x_bf16, int64_t rows, int K, void *q_out, void *scale_out, void *stream) {
+    TSIM_REQUIRE(x_bf16 && q_out && scale_out, "quantize_mxfp8: null pointer");
+    TSIM_REQUIRE(rows >= 0 && K > 0, "quantize_mxfp8: bad shape rows=%lld K=%d", (long long)rows, K);
+    return quant_mx(static_cast<const bf16_t *>(x_bf16), rows, K, static_cast<uint8_t *>(q_out),
+                    static_cast<uint8_t *>(scale_out), reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, const void *ws, const float *bias,
+                               float *out_f32, int M, int N, int K, void *stream) {
+    TSIM_REQUIRE(xq && xs && wq && ws && bias && out_f32, "gemm_mxfp8: null pointer");
+    TSIM_REQUIRE(M >= 0 && N > 0 && K > 0, "gemm_mxfp8: bad shape M=%d N=%d K=%d", M, N, K);
+    return gemm_pp_mx(PP_EPI_F32, static_cast<const uint8_t *>(xq), static_cast<const uint8_t *>(xs),
+                      static_cast<const uint8_t *>(wq), static_cast<const uint8_t *>(ws), bias, out_f32, M, N, K,
+                      reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" void tsim_encoder_destroy(tsim_encoder *e) {
@@ -994,6 +1081,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const tsim_encoder_config &c = e->cfg;
     const int H = c.hidden, F = c.ffn, dh = H / c.heads;
+    const bool mx = c.weight_dtype == TSIM_W_MXFP8;
     int rc;
     if (T > 0) {
         const unsigned g = (unsigned)((T + 3) / 4);
@@ -1008,7 +1096,10 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
         const dim3 agrid((unsigned)B, (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
         for (int l = 0; l < c.num_layers; ++l) {
             const tsim_encoder::Layer &L = e->layers[l];
-            if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
+            if (mx) {   // every projection: quantise its bf16 input to MXFP8, multiply with v_mfma_scale_f32_32x32x64_f8f6f4
+                if ((rc = quant_mx(e->x0, T, H, e->aq, e->as, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, L.sqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
+            } else if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
 #define ATT(D)                                                                                                 \
     do {                                                                                                       \
         if (rel)                                                                                               \
@@ -1021,6 +1112,17 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
             if (dh == 16) ATT(16); else if (dh == 32) ATT(32); else ATT(64);
 #undef ATT
             TSIM_HIP_CHECK(hipGetLastError());
+            if (mx) {
+                if ((rc = quant_mx(e->ctx, T, H, e->aq, e->as, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->aq, e->as, L.qo, L.so, L.bo, e->ybuf, T, H, H, st))) return rc;
+                if ((rc = res_ln_rows(e->ybuf, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, st))) return rc;
+                if ((rc = quant_mx(e->x1, T, H, e->aq, e->as, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_GELU, e->aq, e->as, L.q1, L.s1, L.b1, e->h1, T, F, H, st))) return rc;
+                if ((rc = quant_mx(e->h1, T, F, e->hq, e->hs, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->hq, e->hs, L.q2, L.s2, L.b2, e->ybuf, T, H, F, st))) return rc;
+                if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, st))) return rc;
+                continue;
+            }
             if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
             if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.b1, e->h1, T, F, H, st))) return rc;
             if ((rc = gemm_res_ln(e->h1, L.w2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;

@@ -10,6 +10,14 @@ enum { PP_EPI_BIAS = 0, PP_EPI_GELU = 1, PP_EPI_F32 = 2 };   // bf16 out | bf16 
 bool gemm_pp_supported(int N, int K);
 int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K, hipStream_t st);
 
+// MXFP8 operands (OCP MX: e4m3 elements, one E8M0 scale byte per 32 elements along K; scale arrays [rows, K/32]):
+// N % 256 == 0, K % 128 == 0, K >= 256.  v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16 MFMA rate.
+bool gemm_pp_mx_supported(int N, int K);
+int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, const uint8_t *Ws, const float *bias,
+               void *out, int M, int N, int K, hipStream_t st);
+// bf16 [rows, K] -> MXFP8 bytes [rows, K] + scales [rows, K/32]
+int quant_mx(const bf16_t *x, int64_t rows, int K, uint8_t *q, uint8_t *scales, hipStream_t st);
+
 // out = LayerNorm(y + res) * gamma + beta over rows of H (256, 512, 768, 1024) features.
 int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out, int M,
                 int H, hipStream_t st);

@@ -31,20 +31,39 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
 constexpr int PP_XB = PP_BM * PP_BK * 2, PP_WB = PP_BN * PP_BK * 2, PP_STAGE = PP_XB + PP_WB;   // 32 + 32 KiB
-constexpr int PP_LDS = 2 * PP_STAGE;                                                             // 128 KiB
 constexpr int PP_PPW = PP_STAGE / 1024 / 8;                                                      // DMA pieces per wave and tile
+constexpr int PP_SCALES = 2048;   // MXFP8: per k-tile 256 + 256 rows x 4 E8M0 bytes (one per 32-element block)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
     u32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void glds4(const void *gsrc, void *lds_wave_base) {   // 4 bytes per lane
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
+}
 
-template <int EPI, int KSEC>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+// MX = true: operands are MXFP8 (e4m3 bytes + one E8M0 scale byte per 32 elements along K, scale arrays [rows, K/32]);
+// a tile row is still 128 bytes (128 elements), a k-tile is two v_mfma_scale_f32_32x32x64_f8f6f4 steps.  Operand layout
+// of that instruction, pinned on hardware by tools/microbench/mx_layout.hip: lane (r, h) holds row r, bytes 0-15 of its
+// 8 VGPRs = k 16h..16h+15 (scale block 0), bytes 16-31 = k 32+16h.. (scale block 1); the scale byte a lane supplies
+// (selected by opsel) belongs to block h of its row.
+template <int EPI, int KSEC, bool MX>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X_, const void *__restrict__ W_,
+                                                      const uint8_t *__restrict__ xs, const uint8_t *__restrict__ ws,
                                                       const float *__restrict__ bias, void *__restrict__ out_, int M,
                                                       int N, int K, int mtiles, int ntiles) {
-    constexpr int NSEC = 4 / KSEC;
+    constexpr int ESZ = MX ? 1 : 2;                  // bytes per element
+    constexpr int NSTEP = MX ? 2 : 4;                // MFMA k-steps per k-tile
+    constexpr int NSEC = NSTEP / KSEC;
+    constexpr int STAGE = PP_STAGE + (MX ? PP_SCALES : 0);
     constexpr bool F32 = EPI == PP_EPI_F32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -62,25 +81,38 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16_t *__restrict__
     // ---- LDS image of an operand region: 128-byte tile rows, two per 256-byte super-row, 16-byte chunk c of
     // super-row sr stored at chunk c ^ (sr & 15): the 32 rows x 2 k-halves of a ds_read_b128 fragment hit 16 distinct
     // chunks per 16 lanes (conflict-free).  Piece p = 1 KiB = 64 lanes x 16 B, LDS-linear.
-    int src_off[PP_PPW];
+    // DMA sources: wave-uniform operand base (SGPRs) + one 32-bit byte offset per piece, advanced by 128 per k-tile.
+    uint32_t src_off[PP_PPW];
 #pragma unroll
     for (int i = 0; i < PP_PPW; ++i) {
         const int p = wave + i * 8;                       // < 32: X piece, else W piece
         const int sl = (p & 31) * 64 + lane;
         const int sr = sl >> 4, chp = sl & 15;
         const int ch = chp ^ (sr & 15);
-        src_off[i] = (sr * 2 + (ch >> 3)) * K * 2 + (ch & 7) * 16;
+        src_off[i] = (uint32_t)((sr * 2 + (ch >> 3)) * K * ESZ + (ch & 7) * 16);
     }
-    const char *xbase = reinterpret_cast<const char *>(X + (int64_t)m0 * K);
-    const char *wbase = reinterpret_cast<const char *>(W + (int64_t)n0 * K);
-    auto issue = [&](int kt, int slot) __attribute__((always_inline)) {
+    const char *xbase = reinterpret_cast<const char *>(X_) + (int64_t)m0 * K * ESZ;
+    const char *wbase = reinterpret_cast<const char *>(W_) + (int64_t)n0 * K * ESZ;
+    // MXFP8 scales of a k-tile: one dword (4 blocks) per row; wave w < 4 brings token rows 64w.., wave w >= 4 feature rows
+    const uint8_t *sc_base = nullptr;
+    uint32_t sc_off = 0;
+    if constexpr (MX) {
+        sc_base = wave < 4 ? xs + (int64_t)(m0 + wave * 64) * (K / 32) : ws + (int64_t)(n0 + (wave - 4) * 64) * (K / 32);
+        sc_off = (uint32_t)(lane * (K / 32));
+    }
+    auto issue = [&](int slot) __attribute__((always_inline)) {   // stages the NEXT k-tile (offsets advance by themselves)
 #pragma unroll
         for (int i = 0; i < PP_PPW; ++i) {
             const int p = wave + i * 8;
-            glds16((i < PP_PPW / 2 ? xbase : wbase) + src_off[i] + kt * (PP_BK * 2), smem + slot * PP_STAGE + p * 1024);
+            glds16((i < PP_PPW / 2 ? xbase : wbase) + (size_t)src_off[i], smem + slot * STAGE + p * 1024);
+            src_off[i] += 128;
+        }
+        if constexpr (MX) {
+            glds4(sc_base + (size_t)sc_off, smem + slot * STAGE + PP_STAGE + wave * 256);
+            sc_off += 4;
         }
     };
-    auto frag_off = [&](int row) __attribute__((always_inline)) {   // k-step 0; k-step s: XOR (s << 5)
+    auto frag_off = [&](int row) __attribute__((always_inline)) {   // k-step 0; bf16 k-step s: XOR (s << 5); MX: XOR (s << 6 | q << 5)
         const int sr = row >> 1;
         return (uint32_t)(sr * 256 + ((((row & 1) * 8 + h) ^ (sr & 15)) << 4));
     };
@@ -99,38 +131,70 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16_t *__restrict__
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-    const int nk = K / PP_BK;
-    issue(0, 0);
+    uint32_t xsoff[4], wsoff[2];                     // MX: LDS offsets of this lane's scale dwords
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xsoff[j] = PP_STAGE + (grp * 128 + j * 32 + r) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wsoff[i] = PP_STAGE + 1024 + (wq * 64 + i * 32 + r) * 4;
+
+    const int nk = K * ESZ / 128;
+    issue(0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one interval behind group 0
 
     for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t sbase = lds0 + (kt & 1) * PP_STAGE;
+        const uint32_t sbase = lds0 + (kt & 1) * STAGE;
+        uint32_t xsv[4], wsv[2];
 #pragma unroll
         for (int sec = 0; sec < NSEC; ++sec) {
             // ---------------- L: fragments of KSEC k-steps (+ the next k-tile's DMA)
-            u32x4 xf[KSEC][4], wf[KSEC][2];
+            u32x4 xf[KSEC][4], wf[KSEC][2], xg[KSEC][4], wg[KSEC][2];   // xg/wg: second 16 bytes of an MXFP8 fragment
 #pragma unroll
             for (int ks = 0; ks < KSEC; ++ks) {
-                const uint32_t sx = (uint32_t)((sec * KSEC + ks) << 5);
+                const int st = sec * KSEC + ks;
+                const uint32_t sx = (uint32_t)(MX ? st << 6 : st << 5);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) wf[ks][i] = lds_read_b128(sbase + (woff[i] ^ sx));
+                for (int i = 0; i < 2; ++i) {
+                    wf[ks][i] = lds_read_b128(sbase + (woff[i] ^ sx));
+                    if constexpr (MX) wg[ks][i] = lds_read_b128(sbase + (woff[i] ^ sx ^ 32u));
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xf[ks][j] = lds_read_b128(sbase + (xoff[j] ^ sx));
+                for (int j = 0; j < 4; ++j) {
+                    xf[ks][j] = lds_read_b128(sbase + (xoff[j] ^ sx));
+                    if constexpr (MX) xg[ks][j] = lds_read_b128(sbase + (xoff[j] ^ sx ^ 32u));
+                }
             }
-            if (sec == 0 && kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            if constexpr (MX) {
+                if (sec == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wsv[i] = lds_read_b32(sbase + wsoff[i]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xsv[j] = lds_read_b32(sbase + xsoff[j]);
+                }
+            }
+            if (sec == 0 && kt + 1 < nk) issue((kt + 1) & 1);
             if (sec == NSEC - 1 && grp == 1) wait_vmcnt<0>();
-            if constexpr (KSEC == 1)
+#pragma unroll
+            for (int ks = 0; ks < KSEC; ++ks) {
                 asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3])
+                             : "+v"(wf[ks][0]), "+v"(wf[ks][1]), "+v"(xf[ks][0]), "+v"(xf[ks][1]), "+v"(xf[ks][2]), "+v"(xf[ks][3])
                              :: "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(xf[0][0]), "+v"(xf[0][1]), "+v"(xf[0][2]), "+v"(xf[0][3]),
-                               "+v"(wf[KSEC - 1][0]), "+v"(wf[KSEC - 1][1]), "+v"(xf[KSEC - 1][0]), "+v"(xf[KSEC - 1][1]),
-                               "+v"(xf[KSEC - 1][2]), "+v"(xf[KSEC - 1][3])
-                             :: "memory");
+                if constexpr (MX)
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(wg[ks][0]), "+v"(wg[ks][1]), "+v"(xg[ks][0]), "+v"(xg[ks][1]), "+v"(xg[ks][2]), "+v"(xg[ks][3])
+                                 :: "memory");
+            }
+            if constexpr (MX) {
+                if (sec == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(wsv[0]), "+v"(wsv[1]), "+v"(xsv[0]), "+v"(xsv[1]), "+v"(xsv[2]), "+v"(xsv[3]) :: "memory");
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wsv[i] >>= 8 * h;    // lane half h supplies block h of the step: byte 2s + h
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xsv[j] >>= 8 * h;
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -142,13 +206,30 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const bf16_t *__restrict__
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[ks][i]);
-                        const bf16x8 xv = __builtin_bit_cast(bf16x8, xf[ks][j]);
-                        if constexpr (F32)   // rows (registers) = tokens, columns (lanes) = features
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wv, acc[i][j], 0, 0, 0);
-                        else                 // rows (registers) = features, columns (lanes) = tokens
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
+                        if constexpr (MX) {
+                            const i32x8 wv = __builtin_bit_cast(i32x8, __builtin_shufflevector(wf[ks][i], wg[ks][i], 0, 1, 2, 3, 4, 5, 6, 7));
+                            const i32x8 xv = __builtin_bit_cast(i32x8, __builtin_shufflevector(xf[ks][j], xg[ks][j], 0, 1, 2, 3, 4, 5, 6, 7));
+                            const int st = sec * KSEC + ks;      // opsel = byte 2*st of the (shifted) scale dword
+                            if constexpr (F32) {
+                                if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 0, (int)xsv[j], 0, (int)wsv[i]);
+                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 2, (int)xsv[j], 2, (int)wsv[i]);
+                            } else {
+                                if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, (int)wsv[i], 0, (int)xsv[j]);
+                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 2, (int)wsv[i], 2, (int)xsv[j]);
+                            }
+                        } else {
+                            const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[ks][i]);
+                            const bf16x8 xv = __builtin_bit_cast(bf16x8, xf[ks][j]);
+                            if constexpr (F32)   // rows (registers) = tokens, columns (lanes) = features
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wv, acc[i][j], 0, 0, 0);
+                            else                 // rows (registers) = features, columns (lanes) = tokens
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
+                        }
                     }
+            // keep the cluster inside its barrier interval: without a use here LLVM may sink the (pure) MFMAs into a later
+            // block, merging two sections (seen on the MX variant: 96 fragment VGPRs live, scratch spills)
+            asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[1][0]), "v"(acc[1][1]),
+                         "v"(acc[1][2]), "v"(acc[1][3]));
             __builtin_amdgcn_s_setprio(0);
             if (sec == NSEC - 1 && grp == 0) wait_vmcnt<0>();
             __builtin_amdgcn_sched_barrier(0);
@@ -254,32 +335,81 @@ __global__ __launch_bounds__(256) void res_ln_rows_kernel(const float *__restric
     }
 }
 
-template <int EPI, int KSEC>
-static int launch_pp(const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K, hipStream_t st) {
-    auto kern = gemm_pp_kernel<EPI, KSEC>;
+// bf16 [n] -> MXFP8: e4m3 bytes [n] + E8M0 scale bytes [n / 32] (blocks of 32 consecutive elements; rows are multiples
+// of 32 long, so the flat view is the row view).  8 elements per lane, 4 lanes per block.  Bit-exact restatement:
+// oracle/fp8_ref.mx_quantize.  HBM-bound: 3.03 bytes per element.
+__global__ __launch_bounds__(256) void quant_mx_kernel(const bf16_t *__restrict__ x, int64_t ngroups,
+                                                       uint8_t *__restrict__ q, uint8_t *__restrict__ sc) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // group of 8 elements
+    const bool live = t < ngroups;                                   // ngroups % 4 == 0: a block's 4 lanes agree
+    uint4 raw = make_uint4(0, 0, 0, 0);
+    if (live) raw = *reinterpret_cast<const uint4 *>(x + t * 8);
+    float v[8];
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    // shared exponent floor(log2 amax) - 8, clamped to E8M0's range; amax = 0 -> 0 (scale 1)
+    int sexp = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    sexp = amax > 0.f ? (sexp < -127 ? -127 : sexp) : 0;
+    uint32_t pk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(ldexpf(v[4 * i + e], -sexp), -448.f), 448.f);
+        int o = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+        o = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], o, true);
+        pk[i] = (uint32_t)o;
+    }
+    if (live) {
+        *reinterpret_cast<uint2 *>(q + t * 8) = make_uint2(pk[0], pk[1]);
+        if ((t & 3) == 0) sc[t >> 2] = (uint8_t)(sexp + 127);
+    }
+}
+
+template <int EPI, int KSEC, bool MX>
+static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint8_t *ws, const float *bias, void *out,
+                     int M, int N, int K, hipStream_t st) {
+    constexpr int lds = 2 * (PP_STAGE + (MX ? PP_SCALES : 0));
+    auto kern = gemm_pp_kernel<EPI, KSEC, MX>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
     const int mtiles = (M + PP_BM - 1) / PP_BM, ntiles = N / PP_BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), PP_LDS, st, X, W, bias, out, M, N, K, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, M, N, K, mtiles, ntiles);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
 
 bool gemm_pp_supported(int N, int K) { return N % PP_BN == 0 && K % PP_BK == 0 && K >= 2 * PP_BK; }
+bool gemm_pp_mx_supported(int N, int K) { return N % PP_BN == 0 && K % 128 == 0 && K >= 256; }
+
+static int pp_ksec() {
+    static int ksec = -1;
+    if (ksec < 0) { const char *e = getenv("TSIM_PP_KSEC"); ksec = e ? atoi(e) : 2; }
+    return ksec;
+}
 
 int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K,
             hipStream_t st) {
     if (!gemm_pp_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp: N=%d K=%d not tileable by 256x64", N, K);
     if (M <= 0) return TSIM_OK;
-    static int ksec = -1;
-    if (ksec < 0) { const char *e = getenv("TSIM_PP_KSEC"); ksec = e ? atoi(e) : 2; }
-#define PP_GO(E)                                                                      \
-    return ksec == 1 ? launch_pp<E, 1>(X, W, bias, out, M, N, K, st) : launch_pp<E, 2>(X, W, bias, out, M, N, K, st)
+    const int ksec = pp_ksec();
+#define PP_GO(E)                                                                                   \
+    return ksec == 1 ? launch_pp<E, 1, false>(X, W, nullptr, nullptr, bias, out, M, N, K, st)       \
+                     : launch_pp<E, 2, false>(X, W, nullptr, nullptr, bias, out, M, N, K, st)
     switch (epi) {
         case PP_EPI_BIAS: PP_GO(PP_EPI_BIAS);
         case PP_EPI_GELU: PP_GO(PP_EPI_GELU);
@@ -287,6 +417,27 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
         default: return fail(TSIM_EINVAL, "gemm_pp: unknown epilogue %d", epi);
     }
 #undef PP_GO
+}
+
+int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, const uint8_t *Ws, const float *bias,
+               void *out, int M, int N, int K, hipStream_t st) {
+    if (!gemm_pp_mx_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp_mx: N=%d K=%d not tileable by 256x128", N, K);
+    if (M <= 0) return TSIM_OK;
+    switch (epi) {   // one v_mfma_scale_f32_32x32x64 step (8 MFMAs, 512 cycles) per section
+        case PP_EPI_BIAS: return launch_pp<PP_EPI_BIAS, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
+        case PP_EPI_GELU: return launch_pp<PP_EPI_GELU, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
+        case PP_EPI_F32: return launch_pp<PP_EPI_F32, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
+        default: return fail(TSIM_EINVAL, "gemm_pp_mx: unknown epilogue %d", epi);
+    }
+}
+
+int quant_mx(const bf16_t *x, int64_t rows, int K, uint8_t *q, uint8_t *scales, hipStream_t st) {
+    if (K % 32 != 0) return fail(TSIM_EINVAL, "quant_mx: K=%d is not a multiple of the 32-element block", K);
+    const int64_t ngroups = rows * K / 8;
+    if (ngroups <= 0) return TSIM_OK;
+    hipLaunchKernelGGL(quant_mx_kernel, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, st, x, ngroups, q, scales);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
 }
 
 int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out, int M,

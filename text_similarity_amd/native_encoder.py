@@ -43,7 +43,12 @@ def layer_names(cfg: EncoderConfig, l: int) -> Dict[str, str]:
 
 class NativeEncoder:
     def __init__(self, cfg: EncoderConfig, weights: Dict[str, np.ndarray], max_tokens: int = 65536,
-                 max_seqs: int = 8192, device: Optional[torch.device] = None):
+                 max_seqs: int = 8192, device: Optional[torch.device] = None, weight_dtype: str = "bf16"):
+        """``weight_dtype``: "bf16" (default) or "mxfp8" — projections on OCP MXFP8 operands (e4m3 + one power-of-two
+        scale per 32 elements) through the block-scaled fp8 MFMA; base-size models only (hidden, ffn % 256 == 0)."""
+        if weight_dtype not in ("bf16", "mxfp8"):
+            raise ValueError(f"weight_dtype must be 'bf16' or 'mxfp8', got {weight_dtype!r}")
+        self.weight_dtype = weight_dtype
         if not torch.cuda.is_available():
             raise _lib.TsimError("NativeEncoder needs an MI355X: torch.cuda.is_available() is False and "
                                  "there is no CPU fallback")
@@ -86,7 +91,8 @@ class NativeEncoder:
                                  num_layers=cfg.num_layers, hidden=cfg.hidden, heads=cfg.heads, ffn=cfg.ffn,
                                  vocab=cfg.vocab, max_pos=cfg.max_pos, pad_id=cfg.pad_id,
                                  rel_buckets=cfg.rel_buckets, ln_eps=cfg.ln_eps, max_tokens=self.max_tokens,
-                                 max_seqs=self.max_seqs)
+                                 max_seqs=self.max_seqs,
+                                 weight_dtype=_lib.W_MXFP8 if weight_dtype == "mxfp8" else _lib.W_BF16)
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().tsim_encoder_create(C.byref(cc), C.byref(ew), C.byref(handle)), "encoder_create")

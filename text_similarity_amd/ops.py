@@ -121,3 +121,41 @@ def mean_pool(hidden: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().tsim_mean_pool(hidden.data_ptr(), dt, m.data_ptr(), B, S, H, out.data_ptr(),
                                          _stream(hidden)), "mean_pool")
     return out
+
+
+def quantize_mxfp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[rows, K] bf16 -> (e4m3 bytes uint8 [rows, K], E8M0 block scales uint8 [rows, K/32]) — the operand format of
+    the fp8 encoder variant (``NativeEncoder(weight_dtype="mxfp8")``).  K % 32 == 0."""
+    _need_gpu(x)
+    if x.dim() != 2 or x.dtype != torch.bfloat16:
+        raise ValueError("quantize_mxfp8 expects a 2-D bfloat16 tensor")
+    rows, K = x.shape
+    if K % 32 != 0:
+        raise ValueError(f"K={K} is not a multiple of the 32-element MX block")
+    x = x.contiguous()
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    s = torch.empty((rows, K // 32), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().tsim_quantize_mxfp8(x.data_ptr(), rows, K, q.data_ptr(), s.data_ptr(), _stream(x)),
+                   "quantize_mxfp8")
+    return q, s
+
+
+def gemm_mxfp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """float32 [M, N] = dequant(xq, xs) @ dequant(wq, ws)^T + bias with the block-scaled fp8 MFMA.
+    xq [M, K] / wq [N, K] uint8 e4m3 bytes, xs [M, K/32] / ws [N, K/32] uint8 E8M0 scales, bias float32 [N]."""
+    _need_gpu(xq, xs, wq, ws, bias)
+    M, K = xq.shape
+    N = wq.shape[0]
+    if wq.shape[1] != K or xs.shape != (M, K // 32) or ws.shape != (N, K // 32) or bias.shape != (N,):
+        raise ValueError("gemm_mxfp8: inconsistent operand shapes")
+    Mp = (M + 255) // 256 * 256                      # the kernel works on whole 256-row tiles
+    xqp = torch.zeros((Mp, K), dtype=torch.uint8, device=xq.device)
+    xsp = torch.full((Mp, K // 32), 127, dtype=torch.uint8, device=xq.device)
+    xqp[:M], xsp[:M] = xq, xs
+    out = torch.empty((Mp, N), dtype=torch.float32, device=xq.device)
+    with torch.cuda.device(xq.device):
+        _lib.check(_lib.lib().tsim_gemm_mxfp8(xqp.data_ptr(), xsp.data_ptr(), wq.contiguous().data_ptr(),
+                                              ws.contiguous().data_ptr(), bias.contiguous().data_ptr(), out.data_ptr(),
+                                              M, N, K, _stream(xq)), "gemm_mxfp8")
+    return out[:M]

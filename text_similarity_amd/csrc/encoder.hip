@@ -930,7 +930,7 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, cons
         // fp32 sums and a row kernel adds the residual and normalises (HBM-bound, 8 B per element)
         int rc = gemm_pp(PP_EPI_F32, X, W, bias, ybuf, M, N, K, st);
         if (rc) return rc;
-        return res_ln_rows(ybuf, res, gamma, beta, eps, out, M, N, st);
+        return res_ln_rows(ybuf, res, gamma, beta, eps, out, nullptr, nullptr, M, N, st);
     }
     switch (N) {
         case 384: {
@@ -1058,7 +1058,7 @@ extern "C" int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, c
     TSIM_REQUIRE(xq && xs && wq && ws && bias && out_f32, "gemm_mxfp8: null pointer");
     TSIM_REQUIRE(M >= 0 && N > 0 && K > 0, "gemm_mxfp8: bad shape M=%d N=%d K=%d", M, N, K);
     return gemm_pp_mx(PP_EPI_F32, static_cast<const uint8_t *>(xq), static_cast<const uint8_t *>(xs),
-                      static_cast<const uint8_t *>(wq), static_cast<const uint8_t *>(ws), bias, out_f32, M, N, K,
+                      static_cast<const uint8_t *>(wq), static_cast<const uint8_t *>(ws), bias, out_f32, nullptr, M, N, K,
                       reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1096,9 +1096,10 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
         const dim3 agrid((unsigned)B, (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
         for (int l = 0; l < c.num_layers; ++l) {
             const tsim_encoder::Layer &L = e->layers[l];
-            if (mx) {   // every projection: quantise its bf16 input to MXFP8, multiply with v_mfma_scale_f32_32x32x64_f8f6f4
-                if ((rc = quant_mx(e->x0, T, H, e->aq, e->as, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, L.sqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
+            if (mx) {   // projections on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4); x0's image comes fused from the
+                        // previous layer's LayerNorm kernel, for layer 0 from the stand-alone quantiser
+                if (l == 0 && (rc = quant_mx(e->x0, T, H, e->aq, e->as, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, L.sqkv, L.bqkv, e->qkv, nullptr, T, 3 * H, H, st))) return rc;
             } else if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
 #define ATT(D)                                                                                                 \
     do {                                                                                                       \
@@ -1114,13 +1115,11 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
             TSIM_HIP_CHECK(hipGetLastError());
             if (mx) {
                 if ((rc = quant_mx(e->ctx, T, H, e->aq, e->as, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_F32, e->aq, e->as, L.qo, L.so, L.bo, e->ybuf, T, H, H, st))) return rc;
-                if ((rc = res_ln_rows(e->ybuf, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, st))) return rc;
-                if ((rc = quant_mx(e->x1, T, H, e->aq, e->as, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_GELU, e->aq, e->as, L.q1, L.s1, L.b1, e->h1, T, F, H, st))) return rc;
-                if ((rc = quant_mx(e->h1, T, F, e->hq, e->hs, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_F32, e->hq, e->hs, L.q2, L.s2, L.b2, e->ybuf, T, H, F, st))) return rc;
-                if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->aq, e->as, L.qo, L.so, L.bo, e->ybuf, nullptr, T, H, H, st))) return rc;
+                if ((rc = res_ln_rows(e->ybuf, e->x0, L.g1, L.be1, c.ln_eps, e->x1, e->aq, e->as, T, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_GELU_MX, e->aq, e->as, L.q1, L.s1, L.b1, e->hq, e->hs, T, F, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->hq, e->hs, L.q2, L.s2, L.b2, e->ybuf, nullptr, T, H, F, st))) return rc;
+                if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, e->aq, e->as, T, H, st))) return rc;
                 continue;
             }
             if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;

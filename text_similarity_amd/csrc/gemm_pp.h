@@ -4,7 +4,8 @@
 
 namespace tsim {
 
-enum { PP_EPI_BIAS = 0, PP_EPI_GELU = 1, PP_EPI_F32 = 2 };   // bf16 out | bf16 out after GELU(erf) | fp32 out
+// bf16 out | bf16 out after GELU(erf) | fp32 out | MXFP8 out after GELU (bytes + block scales; MX operands only)
+enum { PP_EPI_BIAS = 0, PP_EPI_GELU = 1, PP_EPI_F32 = 2, PP_EPI_GELU_MX = 3 };
 
 // N % 256 == 0, K % 64 == 0, K >= 128.  Row counts: X, out must be allocated for ceil(M/256)*256 rows.
 bool gemm_pp_supported(int N, int K);
@@ -14,12 +15,13 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
 // N % 256 == 0, K % 128 == 0, K >= 256.  v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16 MFMA rate.
 bool gemm_pp_mx_supported(int N, int K);
 int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, const uint8_t *Ws, const float *bias,
-               void *out, int M, int N, int K, hipStream_t st);
+               void *out, uint8_t *out_scales, int M, int N, int K, hipStream_t st);
 // bf16 [rows, K] -> MXFP8 bytes [rows, K] + scales [rows, K/32]
 int quant_mx(const bf16_t *x, int64_t rows, int K, uint8_t *q, uint8_t *scales, hipStream_t st);
 
 // out = LayerNorm(y + res) * gamma + beta over rows of H (256, 512, 768, 1024) features.
-int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out, int M,
-                int H, hipStream_t st);
+// q / q_scales non-null: the row is also written as MXFP8 (the next projection's operand), fused.
+int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out,
+                uint8_t *q, uint8_t *q_scales, int M, int H, hipStream_t st);
 
 }  // namespace tsim

@@ -50,6 +50,20 @@ __device__ __forceinline__ void glds4(const void *gsrc, void *lds_wave_base) {  
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 4, 0, 0);
 }
 
+// ---- MXFP8 element/scale helpers (bit-exact restatement: oracle/fp8_ref.mx_quantize)
+__device__ __forceinline__ int mx_shared_exp(float amax) {   // floor(log2 amax) - 8, clamped to E8M0; amax = 0 -> 0
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    return amax > 0.f ? (e < -127 ? -127 : e) : 0;
+}
+__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d, int sexp) {
+    const float y0 = fminf(fmaxf(ldexpf(a, -sexp), -448.f), 448.f), y1 = fminf(fmaxf(ldexpf(b, -sexp), -448.f), 448.f);
+    const float y2 = fminf(fmaxf(ldexpf(c, -sexp), -448.f), 448.f), y3 = fminf(fmaxf(ldexpf(d, -sexp), -448.f), 448.f);
+    int o = __builtin_amdgcn_cvt_pk_fp8_f32(y0, y1, 0, false);
+    o = __builtin_amdgcn_cvt_pk_fp8_f32(y2, y3, o, true);
+    return (uint32_t)o;
+}
+__device__ __forceinline__ float bf16_round_f32(float f) { return __uint_as_float((uint32_t)f32_to_bf16(f) << 16); }
+
 // MX = true: operands are MXFP8 (e4m3 bytes + one E8M0 scale byte per 32 elements along K, scale arrays [rows, K/32]);
 // a tile row is still 128 bytes (128 elements), a k-tile is two v_mfma_scale_f32_32x32x64_f8f6f4 steps.  Operand layout
 // of that instruction, pinned on hardware by tools/microbench/mx_layout.hip: lane (r, h) holds row r, bytes 0-15 of its
@@ -58,8 +72,9 @@ __device__ __forceinline__ void glds4(const void *gsrc, void *lds_wave_base) {  
 template <int EPI, int KSEC, bool MX>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X_, const void *__restrict__ W_,
                                                       const uint8_t *__restrict__ xs, const uint8_t *__restrict__ ws,
-                                                      const float *__restrict__ bias, void *__restrict__ out_, int M,
-                                                      int N, int K, int mtiles, int ntiles) {
+                                                      const float *__restrict__ bias, void *__restrict__ out_,
+                                                      uint8_t *__restrict__ out_s, int M, int N, int K, int mtiles,
+                                                      int ntiles) {
     constexpr int ESZ = MX ? 1 : 2;                  // bytes per element
     constexpr int NSTEP = MX ? 2 : 4;                // MFMA k-steps per k-tile
     constexpr int NSEC = NSTEP / KSEC;
@@ -254,6 +269,53 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                     out[m * N + n] = acc[i][j][g] + bv;
                 }
         }
+    } else if constexpr (EPI == PP_EPI_GELU_MX) {
+        // bias + GELU, rounded to bf16 (what the unfused path stores), then straight to MXFP8 — the next projection's
+        // operand format: the 32 features i*32.. of a token are one scale block, 16 values in lane (r, 0) and 16 in
+        // lane (r, 1).  Bytes and scales go through LDS so that global stores are row-contiguous.
+        uint8_t *out = reinterpret_cast<uint8_t *>(out_);
+        constexpr int SC0 = PP_BM * PP_BN;               // scale image [256 tokens][8 blocks] behind the byte image
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 bv[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4 *>(bias + n0 + wq * 64 + i * 32 + 8 * gq + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y[16];
+                float amax = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    y[4 * gq + 0] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 0] + bv[gq].x));
+                    y[4 * gq + 1] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 1] + bv[gq].y));
+                    y[4 * gq + 2] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 2] + bv[gq].z));
+                    y[4 * gq + 3] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 3] + bv[gq].w));
+                }
+#pragma unroll
+                for (int g = 0; g < 16; ++g) amax = fmaxf(amax, fabsf(y[g]));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const int sexp = mx_shared_exp(amax);
+                const int row = grp * 128 + j * 32 + r;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int nloc = wq * 64 + i * 32 + 8 * gq + 4 * h;
+                    *reinterpret_cast<uint32_t *>(smem + row * PP_BN + (((nloc >> 4) ^ (row & 15)) << 4) + (nloc & 15)) =
+                        mx_pack4(y[4 * gq], y[4 * gq + 1], y[4 * gq + 2], y[4 * gq + 3], sexp);
+                }
+                if (h == 0) *reinterpret_cast<uint8_t *>(smem + SC0 + row * 8 + wq * 2 + i) = (uint8_t)(sexp + 127);
+            }
+        }
+        __syncthreads();
+        uint8_t *obase = out + (int64_t)m0 * N + n0;
+#pragma unroll 4
+        for (int sl = threadIdx.x; sl < PP_BM * 16; sl += 512) {
+            const int row = sl >> 4, cp = sl & 15;       // rows past M land in the padded tail of the buffer
+            *reinterpret_cast<uint4 *>(obase + (int64_t)row * N + ((cp ^ (row & 15)) << 4)) =
+                *reinterpret_cast<const uint4 *>(smem + sl * 16);
+        }
+        if (threadIdx.x < PP_BM)
+            *reinterpret_cast<uint2 *>(out_s + (int64_t)(m0 + threadIdx.x) * (N / 32) + n0 / 32) =
+                *reinterpret_cast<const uint2 *>(smem + SC0 + threadIdx.x * 8);
     } else {
         // acc[i][j][g]: feature n0 + wq*64 + i*32 + (g&3) + 8*(g>>2) + 4*h, token m0 + grp*128 + j*32 + r.
         // Tile image in LDS: row = token (512 B), 16-byte slot c at c ^ (row & 15).
@@ -296,10 +358,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
 
 // out[m, :] = LayerNorm(y[m, :] + res[m, :]) * gamma + beta, one wave per token row, fp32 statistics (two-pass).
 // HBM-bound: H * (4 + 2 + 2) bytes per row.
-template <int VPL4>   // float4 groups per lane = H / 256
+template <int VPL4, bool QUANT>   // float4 groups per lane = H / 256; QUANT: also emit the row as MXFP8 (q, sc)
 __global__ __launch_bounds__(256) void res_ln_rows_kernel(const float *__restrict__ y, const bf16_t *__restrict__ res,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, int M, int H, bf16_t *__restrict__ out) {
+                                                          float eps, int M, int H, bf16_t *__restrict__ out,
+                                                          uint8_t *__restrict__ q, uint8_t *__restrict__ sc) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -317,12 +380,12 @@ __global__ __launch_bounds__(256) void res_ln_rows_kernel(const float *__restric
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)H;
-    float q = 0.f;
+    float qs = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q += (v[i][e] - mean) * (v[i][e] - mean);
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        for (int e = 0; e < 4; ++e) qs += (v[i][e] - mean) * (v[i][e] - mean);
+    const float rstd = 1.0f / sqrtf(wave_sum(qs) / (float)H + eps);
 #pragma unroll
     for (int i = 0; i < VPL4; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -332,6 +395,17 @@ __global__ __launch_bounds__(256) void res_ln_rows_kernel(const float *__restric
         o.x = pack_bf16x2((v[i][0] - mean) * rstd * g.x + be.x, (v[i][1] - mean) * rstd * g.y + be.y);
         o.y = pack_bf16x2((v[i][2] - mean) * rstd * g.z + be.z, (v[i][3] - mean) * rstd * g.w + be.w);
         *reinterpret_cast<uint2 *>(out + row * H + c) = o;
+        if constexpr (QUANT) {   // the bf16 values just stored, 32-element block = 8 consecutive lanes
+            const float f0 = __uint_as_float(o.x << 16), f1 = __uint_as_float(o.x & 0xffff0000u);
+            const float f2 = __uint_as_float(o.y << 16), f3 = __uint_as_float(o.y & 0xffff0000u);
+            float amax = fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3)));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+            const int sexp = mx_shared_exp(amax);
+            *reinterpret_cast<uint32_t *>(q + row * H + c) = mx_pack4(f0, f1, f2, f3, sexp);
+            if ((lane & 7) == 0) sc[row * (H / 32) + (c >> 5)] = (uint8_t)(sexp + 127);
+        }
     }
 }
 
@@ -356,19 +430,8 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const bf16_t *__restrict_
     for (int i = 0; i < 8; ++i) amax = fmaxf(amax, fabsf(v[i]));
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
     amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    // shared exponent floor(log2 amax) - 8, clamped to E8M0's range; amax = 0 -> 0 (scale 1)
-    int sexp = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
-    sexp = amax > 0.f ? (sexp < -127 ? -127 : sexp) : 0;
-    uint32_t pk[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fminf(fmaxf(ldexpf(v[4 * i + e], -sexp), -448.f), 448.f);
-        int o = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
-        o = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], o, true);
-        pk[i] = (uint32_t)o;
-    }
+    const int sexp = mx_shared_exp(amax);
+    const uint32_t pk[2] = {mx_pack4(v[0], v[1], v[2], v[3], sexp), mx_pack4(v[4], v[5], v[6], v[7], sexp)};
     if (live) {
         *reinterpret_cast<uint2 *>(q + t * 8) = make_uint2(pk[0], pk[1]);
         if ((t & 3) == 0) sc[t >> 2] = (uint8_t)(sexp + 127);
@@ -377,7 +440,7 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const bf16_t *__restrict_
 
 template <int EPI, int KSEC, bool MX>
 static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint8_t *ws, const float *bias, void *out,
-                     int M, int N, int K, hipStream_t st) {
+                     uint8_t *out_s, int M, int N, int K, hipStream_t st) {
     constexpr int lds = 2 * (PP_STAGE + (MX ? PP_SCALES : 0));
     auto kern = gemm_pp_kernel<EPI, KSEC, MX>;
     static bool attr_done = false;
@@ -388,7 +451,7 @@ static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint
     }
     const int mtiles = (M + PP_BM - 1) / PP_BM, ntiles = N / PP_BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, M, N, K, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, out_s, M, N, K, mtiles, ntiles);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -408,8 +471,8 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
     if (M <= 0) return TSIM_OK;
     const int ksec = pp_ksec();
 #define PP_GO(E)                                                                                   \
-    return ksec == 1 ? launch_pp<E, 1, false>(X, W, nullptr, nullptr, bias, out, M, N, K, st)       \
-                     : launch_pp<E, 2, false>(X, W, nullptr, nullptr, bias, out, M, N, K, st)
+    return ksec == 1 ? launch_pp<E, 1, false>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)       \
+                     : launch_pp<E, 2, false>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)
     switch (epi) {
         case PP_EPI_BIAS: PP_GO(PP_EPI_BIAS);
         case PP_EPI_GELU: PP_GO(PP_EPI_GELU);
@@ -420,13 +483,16 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
 }
 
 int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, const uint8_t *Ws, const float *bias,
-               void *out, int M, int N, int K, hipStream_t st) {
+               void *out, uint8_t *out_scales, int M, int N, int K, hipStream_t st) {
     if (!gemm_pp_mx_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp_mx: N=%d K=%d not tileable by 256x128", N, K);
     if (M <= 0) return TSIM_OK;
     switch (epi) {   // one v_mfma_scale_f32_32x32x64 step (8 MFMAs, 512 cycles) per section
-        case PP_EPI_BIAS: return launch_pp<PP_EPI_BIAS, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
-        case PP_EPI_GELU: return launch_pp<PP_EPI_GELU, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
-        case PP_EPI_F32: return launch_pp<PP_EPI_F32, 1, true>(Xq, Wq, Xs, Ws, bias, out, M, N, K, st);
+        case PP_EPI_BIAS: return launch_pp<PP_EPI_BIAS, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
+        case PP_EPI_GELU: return launch_pp<PP_EPI_GELU, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
+        case PP_EPI_F32: return launch_pp<PP_EPI_F32, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
+        case PP_EPI_GELU_MX:
+            if (!out_scales) return fail(TSIM_EINVAL, "gemm_pp_mx: the MXFP8 epilogue needs a scale output");
+            return launch_pp<PP_EPI_GELU_MX, 1, true>(Xq, Wq, Xs, Ws, bias, out, out_scales, M, N, K, st);
         default: return fail(TSIM_EINVAL, "gemm_pp_mx: unknown epilogue %d", epi);
     }
 }
@@ -440,17 +506,24 @@ int quant_mx(const bf16_t *x, int64_t rows, int K, uint8_t *q, uint8_t *scales, 
     return TSIM_OK;
 }
 
-int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out, int M,
-                int H, hipStream_t st) {
+int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const float *beta, float eps, bf16_t *out,
+                uint8_t *q, uint8_t *q_scales, int M, int H, hipStream_t st) {
     if (M <= 0) return TSIM_OK;
     const unsigned g = (unsigned)((M + 3) / 4);
+    const bool qt = q != nullptr && q_scales != nullptr;
+#define RL_GO(V)                                                                                                          \
+    do {                                                                                                                  \
+        if (qt) hipLaunchKernelGGL((res_ln_rows_kernel<V, true>), dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out, q, q_scales); \
+        else hipLaunchKernelGGL((res_ln_rows_kernel<V, false>), dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out, q, q_scales);   \
+    } while (0)
     switch (H) {
-        case 768: hipLaunchKernelGGL(res_ln_rows_kernel<3>, dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out); break;
-        case 256: hipLaunchKernelGGL(res_ln_rows_kernel<1>, dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out); break;
-        case 512: hipLaunchKernelGGL(res_ln_rows_kernel<2>, dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out); break;
-        case 1024: hipLaunchKernelGGL(res_ln_rows_kernel<4>, dim3(g), dim3(256), 0, st, y, res, gamma, beta, eps, M, H, out); break;
+        case 256: RL_GO(1); break;
+        case 512: RL_GO(2); break;
+        case 768: RL_GO(3); break;
+        case 1024: RL_GO(4); break;
         default: return fail(TSIM_EUNSUPPORTED, "res_ln_rows: hidden size %d (256, 512, 768, 1024)", H);
     }
+#undef RL_GO
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }

@@ -79,6 +79,11 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        # every kernel's host stub must be defined (hipcc has silently dropped one: an undefined symbol only shows at
+        # dlopen time, i.e. on the GPU box) -> load the library once in a child process right after linking
+        chk = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({LIB!r})"], stderr=subprocess.PIPE, text=True)
+        if chk.returncode != 0:
+            raise RuntimeError(f"{LIB} does not load: {chk.stderr.strip().splitlines()[-1] if chk.stderr.strip() else chk.returncode}")
     return LIB
 
 

@@ -909,12 +909,11 @@ static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t
 template <int EPI>
 static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, int K,
                       hipStream_t st) {
-    static int use_xres = -1;
+    static int use_xres = -1, big = -1;
     if (use_xres < 0) { const char *e = getenv("TSIM_GEMM_XRES"); use_xres = e ? atoi(e) : 1; }
-    if (use_xres && K == 384 && N % XR_BN == 0) return gemm_xres<EPI>(X, W, bias, out, M, N, st);
-    static int big = -1;
     if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
-    if (big && K >= 768 && gemm_pp_supported(N, K))
+    if (use_xres && big != 2 && K == 384 && N % XR_BN == 0) return gemm_xres<EPI>(X, W, bias, out, M, N, st);
+    if (big && (K >= 768 || big == 2) && gemm_pp_supported(N, K))
         return gemm_pp(EPI == EPI_GELU ? PP_EPI_GELU : PP_EPI_BIAS, X, W, bias, out, M, N, K, st);
     if (N % 128 == 0)
         return launch_gemm<128, 128, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
@@ -925,7 +924,7 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, cons
                        const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf, hipStream_t st) {
     static int big = -1;
     if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
-    if (big && ybuf && N >= 512 && gemm_pp_supported(N, K)) {
+    if (big && ybuf && N >= 512 && N % 256 == 0 && gemm_pp_supported(N, K)) {
         // wide rows: a workgroup cannot own whole 768-feature rows at a 256-token tile, so the projection writes
         // fp32 sums and a row kernel adds the residual and normalises (HBM-bound, 8 B per element)
         int rc = gemm_pp(PP_EPI_F32, X, W, bias, ybuf, M, N, K, st);
@@ -1030,7 +1029,7 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
         if ((rc = dev_alloc(e, a.n * 2, (void **)a.p))) return bail(rc);
         if (hipMemset(*a.p, 0, a.n * 2) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
     }
-    if (H >= 512 && gemm_pp_supported(H, H)) {
+    if (H >= 512 && H % 256 == 0 && gemm_pp_supported(H, H)) {
         if ((rc = dev_alloc(e, Tp * H * 4, (void **)&e->ybuf))) return bail(rc);
         if (hipMemset(e->ybuf, 0, Tp * H * 4) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
     }

@@ -7,7 +7,7 @@ namespace tsim {
 // bf16 out | bf16 out after GELU(erf) | fp32 out | MXFP8 out after GELU (bytes + block scales; MX operands only)
 enum { PP_EPI_BIAS = 0, PP_EPI_GELU = 1, PP_EPI_F32 = 2, PP_EPI_GELU_MX = 3 };
 
-// N % 256 == 0, K % 64 == 0, K >= 128.  Row counts: X, out must be allocated for ceil(M/256)*256 rows.
+// N % 128 == 0, K % 64 == 0, K >= 128.  Row counts: X, out must be allocated for ceil(M/256)*256 rows.
 bool gemm_pp_supported(int N, int K);
 int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K, hipStream_t st);
 

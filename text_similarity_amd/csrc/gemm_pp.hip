@@ -29,9 +29,8 @@ namespace tsim {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
-constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64;
-constexpr int PP_XB = PP_BM * PP_BK * 2, PP_WB = PP_BN * PP_BK * 2, PP_STAGE = PP_XB + PP_WB;   // 32 + 32 KiB
-constexpr int PP_PPW = PP_STAGE / 1024 / 8;                                                      // DMA pieces per wave and tile
+constexpr int PP_BM = 256, PP_BK = 64;          // token tile, k-tile (128 bytes per tile row); feature tile BN = 256 or 128
+constexpr int PP_XB = PP_BM * PP_BK * 2;        // 32 KiB of token rows per stage
 constexpr int PP_SCALES = 2048;   // MXFP8: per k-tile 256 + 256 rows x 4 E8M0 bytes (one per 32-element block)
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
@@ -40,9 +39,16 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
-__device__ __forceinline__ uint32_t lds_read_b32(uint32_t addr) {
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_o(uint32_t addr) {   // address + immediate byte offset (< 65536)
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_read_b32_o(uint32_t addr) {
     uint32_t v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 __device__ __forceinline__ void glds4(const void *gsrc, void *lds_wave_base) {   // 4 bytes per lane
@@ -69,7 +75,7 @@ __device__ __forceinline__ float bf16_round_f32(float f) { return __uint_as_floa
 // of that instruction, pinned on hardware by tools/microbench/mx_layout.hip: lane (r, h) holds row r, bytes 0-15 of its
 // 8 VGPRs = k 16h..16h+15 (scale block 0), bytes 16-31 = k 32+16h.. (scale block 1); the scale byte a lane supplies
 // (selected by opsel) belongs to block h of its row.
-template <int EPI, int KSEC, bool MX>
+template <int EPI, int KSEC, bool MX, int BN>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X_, const void *__restrict__ W_,
                                                       const uint8_t *__restrict__ xs, const uint8_t *__restrict__ ws,
                                                       const float *__restrict__ bias, void *__restrict__ out_,
@@ -78,26 +84,43 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
     constexpr int ESZ = MX ? 1 : 2;                  // bytes per element
     constexpr int NSTEP = MX ? 2 : 4;                // MFMA k-steps per k-tile
     constexpr int NSEC = NSTEP / KSEC;
+    constexpr int NI = BN / 128;                     // 32-feature fragments per wave (4 waves across the feature tile)
+    constexpr int WFEAT = BN / 4;                    // features per wave
+    constexpr int PP_STAGE = PP_XB + BN * 128;       // operand bytes per stage
+    constexpr int PP_PPW = PP_STAGE / 1024 / 8;      // DMA pieces per wave and k-tile (first 4: token rows)
     constexpr int STAGE = PP_STAGE + (MX ? PP_SCALES : 0);
     constexpr bool F32 = EPI == PP_EPI_F32;
+    static_assert(BN == 256 || BN == 128, "feature tile");
+    static_assert(!MX || BN == 256, "the MXFP8 variant is built for 256-feature tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wq = wave & 3;
     const int r = lane & 31, h = lane >> 5;
 
-    // tile order: the ntiles feature tiles of one token tile share blockIdx % 8, i.e. one XCD's L2 (speed only)
-    const int b = blockIdx.x, xcd = b & 7, jj = b >> 3;
-    const int nt_id = jj % ntiles;
-    const int mt_id = (jj / ntiles) * 8 + xcd;
-    if (mt_id >= mtiles) return;
-    const int m0 = mt_id * PP_BM, n0 = nt_id * PP_BN;
+    // Persistent workgroups: tile indices t = blockIdx.x, + gridDim.x, ... (gridDim.x % 8 == 0, so a workgroup's tiles
+    // keep blockIdx % 8, i.e. their XCD).  Tile order: the ntiles feature tiles of one token tile share t % 8, so they
+    // meet in one XCD's L2 (speed only).
+    const int total = ((mtiles + 7) / 8) * 8 * ntiles;
+    auto tile_at = [&](int t, int &m0, int &n0) __attribute__((always_inline)) {
+        const int xcd = t & 7, jj = t >> 3;
+        const int mt_id = (jj / ntiles) * 8 + xcd;
+        m0 = mt_id * PP_BM;
+        n0 = (jj % ntiles) * BN;
+        return mt_id < mtiles;
+    };
+    auto next_tile = [&](int t) __attribute__((always_inline)) {   // next valid tile of this workgroup, or >= total
+        int m, n;
+        do t += (int)gridDim.x; while (t < total && !tile_at(t, m, n));
+        return t;
+    };
 
     // ---- LDS image of an operand region: 128-byte tile rows, two per 256-byte super-row, 16-byte chunk c of
     // super-row sr stored at chunk c ^ (sr & 15): the 32 rows x 2 k-halves of a ds_read_b128 fragment hit 16 distinct
     // chunks per 16 lanes (conflict-free).  Piece p = 1 KiB = 64 lanes x 16 B, LDS-linear.
     // DMA sources: wave-uniform operand base (SGPRs) + one 32-bit byte offset per piece, advanced by 128 per k-tile.
     uint32_t src_off[PP_PPW];
+    uint32_t advanced = 0;                                // bytes the offsets have moved since they were set
 #pragma unroll
     for (int i = 0; i < PP_PPW; ++i) {
         const int p = wave + i * 8;                       // < 32: X piece, else W piece
@@ -106,22 +129,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
         const int ch = chp ^ (sr & 15);
         src_off[i] = (uint32_t)((sr * 2 + (ch >> 3)) * K * ESZ + (ch & 7) * 16);
     }
-    const char *xbase = reinterpret_cast<const char *>(X_) + (int64_t)m0 * K * ESZ;
-    const char *wbase = reinterpret_cast<const char *>(W_) + (int64_t)n0 * K * ESZ;
+    const char *xbase = nullptr, *wbase = nullptr;
     // MXFP8 scales of a k-tile: one dword (4 blocks) per row; wave w < 4 brings token rows 64w.., wave w >= 4 feature rows
     const uint8_t *sc_base = nullptr;
     uint32_t sc_off = 0;
-    if constexpr (MX) {
-        sc_base = wave < 4 ? xs + (int64_t)(m0 + wave * 64) * (K / 32) : ws + (int64_t)(n0 + (wave - 4) * 64) * (K / 32);
-        sc_off = (uint32_t)(lane * (K / 32));
-    }
+    auto set_sources = [&](int m0, int n0) __attribute__((always_inline)) {
+        xbase = reinterpret_cast<const char *>(X_) + (int64_t)m0 * K * ESZ;
+        wbase = reinterpret_cast<const char *>(W_) + (int64_t)n0 * K * ESZ;
+#pragma unroll
+        for (int i = 0; i < PP_PPW; ++i) src_off[i] -= advanced;
+        advanced = 0;
+        if constexpr (MX) {
+            sc_base = wave < 4 ? xs + (int64_t)(m0 + wave * 64) * (K / 32) : ws + (int64_t)(n0 + (wave - 4) * 64) * (K / 32);
+            sc_off = (uint32_t)(lane * (K / 32));
+        }
+    };
     auto issue = [&](int slot) __attribute__((always_inline)) {   // stages the NEXT k-tile (offsets advance by themselves)
 #pragma unroll
         for (int i = 0; i < PP_PPW; ++i) {
             const int p = wave + i * 8;
-            glds16((i < PP_PPW / 2 ? xbase : wbase) + (size_t)src_off[i], smem + slot * STAGE + p * 1024);
+            glds16((i < 4 ? xbase : wbase) + (size_t)src_off[i], smem + slot * STAGE + p * 1024);
             src_off[i] += 128;
         }
+        advanced += 128;
         if constexpr (MX) {
             glds4(sc_base + (size_t)sc_off, smem + slot * STAGE + PP_STAGE + wave * 256);
             sc_off += 4;
@@ -132,228 +162,291 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
         return (uint32_t)(sr * 256 + ((((row & 1) * 8 + h) ^ (sr & 15)) << 4));
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
-    uint32_t xoff[4], woff[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xoff[j] = frag_off(grp * 128 + j * 32 + r);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) woff[i] = PP_XB + frag_off(wq * 64 + i * 32 + r);
+    // fragment j of this lane sits 32 tile rows = 4096 bytes after fragment 0 (the swizzle term only sees row bits 1-4),
+    // so one address VGPR per operand and immediate offsets address all of them
+    const uint32_t xoff0 = frag_off(grp * 128 + r);
+    const uint32_t woff0 = PP_XB + frag_off(wq * WFEAT + r);
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-
-    uint32_t xsoff[4], wsoff[2];                     // MX: LDS offsets of this lane's scale dwords
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xsoff[j] = PP_STAGE + (grp * 128 + j * 32 + r) * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wsoff[i] = PP_STAGE + 1024 + (wq * 64 + i * 32 + r) * 4;
+    const uint32_t xsoff0 = PP_STAGE + (grp * 128 + r) * 4;            // MX: this lane's scale dwords, +128 per fragment
+    const uint32_t wsoff0 = PP_STAGE + 1024 + (wq * WFEAT + r) * 4;
 
     const int nk = K * ESZ / 128;
+    // Epilogue staging: when it has LDS of its own (PIPE) the next tile's first k-tile is fetched DURING the epilogue.
+    constexpr bool PIPE = F32 || BN == 128;
+    constexpr int STG = PIPE ? 2 * STAGE : 0;
+    int t = blockIdx.x, m0, n0;
+    if (!tile_at(t, m0, n0)) t = next_tile(t);
+    if (t >= total) return;
+    (void)tile_at(t, m0, n0);
+    set_sources(m0, n0);
+    uint32_t kidx = 0;                                    // k-tiles consumed so far: slot parity across tiles
+    constexpr int EPI_STORES = F32 ? NI * 64 : PP_BM * (BN / 8) / 512;   // global stores per wave in one epilogue
+    bool first = true;
     issue(0);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one interval behind group 0
+    for (;;) {
+        f32x16 acc[NI][4];
+    #pragma unroll
+        for (int i = 0; i < NI; ++i)
+    #pragma unroll
+            for (int j = 0; j < 4; ++j)
+    #pragma unroll
+                for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+        // my pieces of this tile's first k-tile have landed.  They are OLDER than the previous epilogue's global stores
+        // when the fetch was issued ahead of them (PIPE): leave those stores in flight (vmcnt is in order, 6 bits wide)
+        if (first || !PIPE) wait_vmcnt<0>(); else wait_vmcnt<(EPI_STORES < 63 ? EPI_STORES : 63)>();
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one interval behind group 0
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const uint32_t sbase = lds0 + (kt & 1) * STAGE;
-        uint32_t xsv[4], wsv[2];
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint32_t sbase = lds0 + ((kidx + kt) & 1) * STAGE;
+            uint32_t xsv[4], wsv[NI];
 #pragma unroll
-        for (int sec = 0; sec < NSEC; ++sec) {
-            // ---------------- L: fragments of KSEC k-steps (+ the next k-tile's DMA)
-            u32x4 xf[KSEC][4], wf[KSEC][2], xg[KSEC][4], wg[KSEC][2];   // xg/wg: second 16 bytes of an MXFP8 fragment
+            for (int sec = 0; sec < NSEC; ++sec) {
+                // ---------------- L: fragments of KSEC k-steps (+ the next k-tile's DMA)
+                u32x4 xf[KSEC][4], wf[KSEC][NI], xg[KSEC][4], wg[KSEC][NI];   // xg/wg: second 16 bytes of an MXFP8 fragment
 #pragma unroll
-            for (int ks = 0; ks < KSEC; ++ks) {
-                const int st = sec * KSEC + ks;
-                const uint32_t sx = (uint32_t)(MX ? st << 6 : st << 5);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    wf[ks][i] = lds_read_b128(sbase + (woff[i] ^ sx));
-                    if constexpr (MX) wg[ks][i] = lds_read_b128(sbase + (woff[i] ^ sx ^ 32u));
+                for (int ks = 0; ks < KSEC; ++ks) {
+                    const int st = sec * KSEC + ks;
+                    const uint32_t sx = (uint32_t)(MX ? st << 6 : st << 5);
+                    const uint32_t wa = sbase + (woff0 ^ sx), xa = sbase + (xoff0 ^ sx);
+                    wf[ks][0] = lds_read_b128_o<0>(wa);
+                    if constexpr (NI == 2) wf[ks][NI - 1] = lds_read_b128_o<4096>(wa);
+                    xf[ks][0] = lds_read_b128_o<0>(xa);
+                    xf[ks][1] = lds_read_b128_o<4096>(xa);
+                    xf[ks][2] = lds_read_b128_o<8192>(xa);
+                    xf[ks][3] = lds_read_b128_o<12288>(xa);
+                    if constexpr (MX) {   // second 16 bytes of each 32-byte fragment: chunk + 2
+                        const uint32_t wb = sbase + (woff0 ^ sx ^ 32u), xb = sbase + (xoff0 ^ sx ^ 32u);
+                        wg[ks][0] = lds_read_b128_o<0>(wb);
+                        if constexpr (NI == 2) wg[ks][NI - 1] = lds_read_b128_o<4096>(wb);
+                        xg[ks][0] = lds_read_b128_o<0>(xb);
+                        xg[ks][1] = lds_read_b128_o<4096>(xb);
+                        xg[ks][2] = lds_read_b128_o<8192>(xb);
+                        xg[ks][3] = lds_read_b128_o<12288>(xb);
+                    }
                 }
+                if constexpr (MX) {
+                    if (sec == 0) {
+                        wsv[0] = lds_read_b32_o<0>(sbase + wsoff0);
+                        if constexpr (NI == 2) wsv[NI - 1] = lds_read_b32_o<128>(sbase + wsoff0);
+                        xsv[0] = lds_read_b32_o<0>(sbase + xsoff0);
+                        xsv[1] = lds_read_b32_o<128>(sbase + xsoff0);
+                        xsv[2] = lds_read_b32_o<256>(sbase + xsoff0);
+                        xsv[3] = lds_read_b32_o<384>(sbase + xsoff0);
+                    }
+                }
+                if (sec == 0 && kt + 1 < nk) issue((kidx + kt + 1) & 1);
+                if (sec == NSEC - 1 && grp == 1) wait_vmcnt<0>();
+#pragma unroll
+                for (int ks = 0; ks < KSEC; ++ks) {
+                    // the wait carries the fragments as operands so that no MFMA reading them is scheduled above it
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xf[ks][0]), "+v"(xf[ks][1]), "+v"(xf[ks][2]), "+v"(xf[ks][3]) :: "memory");
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(wf[ks][i]));
+                    if constexpr (MX) {
+                        asm volatile("" : "+v"(xg[ks][0]), "+v"(xg[ks][1]), "+v"(xg[ks][2]), "+v"(xg[ks][3]));
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(wg[ks][i]));
+                    }
+                }
+                if constexpr (MX) {
+                    if (sec == 0) {
+                        asm volatile("" : "+v"(xsv[0]), "+v"(xsv[1]), "+v"(xsv[2]), "+v"(xsv[3]));
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(wsv[i]));
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) wsv[i] >>= 8 * h;    // lane half h supplies block h of the step: byte 2s + h
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xsv[j] >>= 8 * h;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---------------- M
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < KSEC; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (MX) {
+                                const i32x8 wv = __builtin_bit_cast(i32x8, __builtin_shufflevector(wf[ks][i], wg[ks][i], 0, 1, 2, 3, 4, 5, 6, 7));
+                                const i32x8 xv = __builtin_bit_cast(i32x8, __builtin_shufflevector(xf[ks][j], xg[ks][j], 0, 1, 2, 3, 4, 5, 6, 7));
+                                const int st = sec * KSEC + ks;      // opsel = byte 2*st of the (shifted) scale dword
+                                if constexpr (F32) {
+                                    if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 0, (int)xsv[j], 0, (int)wsv[i]);
+                                    else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 2, (int)xsv[j], 2, (int)wsv[i]);
+                                } else {
+                                    if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, (int)wsv[i], 0, (int)xsv[j]);
+                                    else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 2, (int)wsv[i], 2, (int)xsv[j]);
+                                }
+                            } else {
+                                const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[ks][i]);
+                                const bf16x8 xv = __builtin_bit_cast(bf16x8, xf[ks][j]);
+                                if constexpr (F32)   // rows (registers) = tokens, columns (lanes) = features
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wv, acc[i][j], 0, 0, 0);
+                                else                 // rows (registers) = features, columns (lanes) = tokens
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
+                            }
+                        }
+                // keep the cluster inside its barrier interval: without a use here LLVM may sink the (pure) MFMAs into a later
+                // block, merging two sections (seen on the MX variant: 96 fragment VGPRs live, scratch spills)
+                // (in/out operands, no loop: with input-only operands of the template-sized array hipcc's host pass silently
+                // drops the kernel's host stub — the library then fails to load with an undefined symbol)
+                asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));
+                if constexpr (NI == 2) asm volatile("" : "+v"(acc[NI - 1][0]), "+v"(acc[NI - 1][1]), "+v"(acc[NI - 1][2]), "+v"(acc[NI - 1][3]));
+                __builtin_amdgcn_s_setprio(0);
+                if (sec == NSEC - 1 && grp == 0) wait_vmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier: everyone is done with LDS
+        kidx += nk;
+        const int tn = next_tile(t);
+        int m0n = 0, n0n = 0;
+        if (tn < total) (void)tile_at(tn, m0n, n0n);
+
+        if constexpr (F32) {
+            // acc[i][j][g]: token m0 + grp*128 + j*32 + (g&3) + 8*(g>>2) + 4*h, feature n0 + wq*WFEAT + i*32 + r
+            float *out = reinterpret_cast<float *>(out_);
+            float bv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)   // asm load: an ordinary load's use would make hipcc drain the DMA issued below
+                asm volatile("global_load_dword %0, %1, off" : "=v"(bv[i]) : "v"(bias + n0 + wq * WFEAT + i * 32 + r) : "memory");
+            if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+            if (tn < total) wait_vmcnt<PP_PPW + (MX ? 1 : 0)>(); else wait_vmcnt<0>();   // the bias loads are older than the DMA
+#pragma unroll
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bv[i]));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = n0 + wq * WFEAT + i * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int64_t m = m0 + grp * 128 + j * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;   // < padded row count
+                        out[m * N + n] = acc[i][j][g] + bv[i];
+                    }
+            }
+        } else if constexpr (EPI == PP_EPI_GELU_MX) {
+            // bias + GELU, rounded to bf16 (what the unfused path stores), then straight to MXFP8 — the next projection's
+            // operand format: the 32 features i*32.. of a token are one scale block, 16 values in lane (r, 0) and 16 in
+            // lane (r, 1).  Bytes and scales go through LDS so that global stores are row-contiguous.
+            uint8_t *out = reinterpret_cast<uint8_t *>(out_);
+            constexpr int SC0 = PP_BM * BN;               // scale image [256 tokens][8 blocks] behind the byte image
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float4 bv[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4 *>(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xf[ks][j] = lds_read_b128(sbase + (xoff[j] ^ sx));
-                    if constexpr (MX) xg[ks][j] = lds_read_b128(sbase + (xoff[j] ^ sx ^ 32u));
+                    float y[16];
+                    float amax = 0.f;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        y[4 * gq + 0] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 0] + bv[gq].x));
+                        y[4 * gq + 1] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 1] + bv[gq].y));
+                        y[4 * gq + 2] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 2] + bv[gq].z));
+                        y[4 * gq + 3] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 3] + bv[gq].w));
+                    }
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) amax = fmaxf(amax, fabsf(y[g]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    const int sexp = mx_shared_exp(amax);
+                    const int row = grp * 128 + j * 32 + r;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int nloc = wq * WFEAT + i * 32 + 8 * gq + 4 * h;
+                        *reinterpret_cast<uint32_t *>(smem + row * BN + (((nloc >> 4) ^ (row & 15)) << 4) + (nloc & 15)) =
+                            mx_pack4(y[4 * gq], y[4 * gq + 1], y[4 * gq + 2], y[4 * gq + 3], sexp);
+                    }
+                    if (h == 0) *reinterpret_cast<uint8_t *>(smem + SC0 + row * 8 + wq * NI + i) = (uint8_t)(sexp + 127);
                 }
             }
-            if constexpr (MX) {
-                if (sec == 0) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) wsv[i] = lds_read_b32(sbase + wsoff[i]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) xsv[j] = lds_read_b32(sbase + xsoff[j]);
-                }
+            __syncthreads();
+            uint8_t *obase = out + (int64_t)m0 * N + n0;
+#pragma unroll 4
+            for (int sl = threadIdx.x; sl < PP_BM * 16; sl += 512) {
+                const int row = sl >> 4, cp = sl & 15;       // rows past M land in the padded tail of the buffer
+                *reinterpret_cast<uint4 *>(obase + (int64_t)row * N + ((cp ^ (row & 15)) << 4)) =
+                    *reinterpret_cast<const uint4 *>(smem + sl * 16);
             }
-            if (sec == 0 && kt + 1 < nk) issue((kt + 1) & 1);
-            if (sec == NSEC - 1 && grp == 1) wait_vmcnt<0>();
+            if (threadIdx.x < PP_BM)
+                *reinterpret_cast<uint2 *>(out_s + (int64_t)(m0 + threadIdx.x) * (N / 32) + n0 / 32) =
+                    *reinterpret_cast<const uint2 *>(smem + SC0 + threadIdx.x * 8);
+            __syncthreads();                                  // the image is read: the slots may be refilled
+            if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+        } else {
+            // acc[i][j][g]: feature n0 + wq*WFEAT + i*32 + (g&3) + 8*(g>>2) + 4*h, token m0 + grp*128 + j*32 + r.
+            // Tile image in LDS (at STG): row = token (BN*2 bytes), 16-byte slot c at c ^ (row & 15).  LDS traffic by inline
+            // asm and raw barriers, bias by asm loads issued BEFORE the prefetch DMA: nothing here drains that DMA.
+            bf16_t *out = reinterpret_cast<bf16_t *>(out_);
+            u32x4 bvr[PIPE ? NI : 1][4];
+            if constexpr (PIPE) {
 #pragma unroll
-            for (int ks = 0; ks < KSEC; ++ks) {
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(wf[ks][0]), "+v"(wf[ks][1]), "+v"(xf[ks][0]), "+v"(xf[ks][1]), "+v"(xf[ks][2]), "+v"(xf[ks][3])
-                             :: "memory");
-                if constexpr (MX)
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(wg[ks][0]), "+v"(wg[ks][1]), "+v"(xg[ks][0]), "+v"(xg[ks][1]), "+v"(xg[ks][2]), "+v"(xg[ks][3])
-                                 :: "memory");
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        asm volatile("global_load_dwordx4 %0, %1, off"
+                                     : "=v"(bvr[i][gq]) : "v"(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h) : "memory");
+                if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+                if (tn < total) wait_vmcnt<PP_PPW + (MX ? 1 : 0)>(); else wait_vmcnt<0>();   // the bias loads are older
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bvr[i][0]), "+v"(bvr[i][1]), "+v"(bvr[i][2]), "+v"(bvr[i][3]));
             }
-            if constexpr (MX) {
-                if (sec == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(wsv[0]), "+v"(wsv[1]), "+v"(xsv[0]), "+v"(xsv[1]), "+v"(xsv[2]), "+v"(xsv[3]) :: "memory");
+            const uint32_t stg = lds0 + STG;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) wsv[i] >>= 8 * h;    // lane half h supplies block h of the step: byte 2s + h
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xsv[j] >>= 8 * h;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- M
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < KSEC; ++ks)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int nloc = wq * WFEAT + i * 32 + 8 * gq + 4 * h;
+                    f32x4 bv;
+                    if constexpr (PIPE) bv = __builtin_bit_cast(f32x4, bvr[i][gq]);
+                    else bv = *reinterpret_cast<const f32x4 *>(bias + n0 + nloc);   // no DMA in flight: an ordinary load
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr (MX) {
-                            const i32x8 wv = __builtin_bit_cast(i32x8, __builtin_shufflevector(wf[ks][i], wg[ks][i], 0, 1, 2, 3, 4, 5, 6, 7));
-                            const i32x8 xv = __builtin_bit_cast(i32x8, __builtin_shufflevector(xf[ks][j], xg[ks][j], 0, 1, 2, 3, 4, 5, 6, 7));
-                            const int st = sec * KSEC + ks;      // opsel = byte 2*st of the (shifted) scale dword
-                            if constexpr (F32) {
-                                if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 0, (int)xsv[j], 0, (int)wsv[i]);
-                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, wv, acc[i][j], 0, 0, 2, (int)xsv[j], 2, (int)wsv[i]);
-                            } else {
-                                if (st == 0) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 0, (int)wsv[i], 0, (int)xsv[j]);
-                                else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc[i][j], 0, 0, 2, (int)wsv[i], 2, (int)xsv[j]);
-                            }
-                        } else {
-                            const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[ks][i]);
-                            const bf16x8 xv = __builtin_bit_cast(bf16x8, xf[ks][j]);
-                            if constexpr (F32)   // rows (registers) = tokens, columns (lanes) = features
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xv, wv, acc[i][j], 0, 0, 0);
-                            else                 // rows (registers) = features, columns (lanes) = tokens
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[i][j], 0, 0, 0);
+                        float y0 = acc[i][j][4 * gq + 0] + bv[0], y1 = acc[i][j][4 * gq + 1] + bv[1];
+                        float y2 = acc[i][j][4 * gq + 2] + bv[2], y3 = acc[i][j][4 * gq + 3] + bv[3];
+                        if constexpr (EPI == PP_EPI_GELU) {
+                            y0 = gelu_erf(y0);
+                            y1 = gelu_erf(y1);
+                            y2 = gelu_erf(y2);
+                            y3 = gelu_erf(y3);
                         }
+                        const uint64_t o = (uint64_t)pack_bf16x2(y0, y1) | ((uint64_t)pack_bf16x2(y2, y3) << 32);
+                        const int row = grp * 128 + j * 32 + r;
+                        const uint32_t ad = stg + row * (BN * 2) + (((nloc >> 3) ^ (row & 15)) << 4) + ((nloc & 4) << 1);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
                     }
-            // keep the cluster inside its barrier interval: without a use here LLVM may sink the (pure) MFMAs into a later
-            // block, merging two sections (seen on the MX variant: 96 fragment VGPRs live, scratch spills)
-            asm volatile("" ::"v"(acc[0][0]), "v"(acc[0][1]), "v"(acc[0][2]), "v"(acc[0][3]), "v"(acc[1][0]), "v"(acc[1][1]),
-                         "v"(acc[1][2]), "v"(acc[1][3]));
-            __builtin_amdgcn_s_setprio(0);
-            if (sec == NSEC - 1 && grp == 0) wait_vmcnt<0>();
-            __builtin_amdgcn_sched_barrier(0);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();           // pairs with group 1's last barrier: everyone is done with LDS
-
-    if constexpr (F32) {
-        // acc[i][j][g]: token m0 + grp*128 + j*32 + (g&3) + 8*(g>>2) + 4*h, feature n0 + wq*64 + i*32 + r
-        float *out = reinterpret_cast<float *>(out_);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int n = n0 + wq * 64 + i * 32 + r;
-            const float bv = bias[n];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int64_t m = m0 + grp * 128 + j * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;   // < padded row count
-                    out[m * N + n] = acc[i][j][g] + bv;
-                }
-        }
-    } else if constexpr (EPI == PP_EPI_GELU_MX) {
-        // bias + GELU, rounded to bf16 (what the unfused path stores), then straight to MXFP8 — the next projection's
-        // operand format: the 32 features i*32.. of a token are one scale block, 16 values in lane (r, 0) and 16 in
-        // lane (r, 1).  Bytes and scales go through LDS so that global stores are row-contiguous.
-        uint8_t *out = reinterpret_cast<uint8_t *>(out_);
-        constexpr int SC0 = PP_BM * PP_BN;               // scale image [256 tokens][8 blocks] behind the byte image
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float4 bv[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4 *>(bias + n0 + wq * 64 + i * 32 + 8 * gq + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y[16];
-                float amax = 0.f;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    y[4 * gq + 0] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 0] + bv[gq].x));
-                    y[4 * gq + 1] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 1] + bv[gq].y));
-                    y[4 * gq + 2] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 2] + bv[gq].z));
-                    y[4 * gq + 3] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 3] + bv[gq].w));
-                }
-#pragma unroll
-                for (int g = 0; g < 16; ++g) amax = fmaxf(amax, fabsf(y[g]));
-                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-                const int sexp = mx_shared_exp(amax);
-                const int row = grp * 128 + j * 32 + r;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int nloc = wq * 64 + i * 32 + 8 * gq + 4 * h;
-                    *reinterpret_cast<uint32_t *>(smem + row * PP_BN + (((nloc >> 4) ^ (row & 15)) << 4) + (nloc & 15)) =
-                        mx_pack4(y[4 * gq], y[4 * gq + 1], y[4 * gq + 2], y[4 * gq + 3], sexp);
-                }
-                if (h == 0) *reinterpret_cast<uint8_t *>(smem + SC0 + row * 8 + wq * 2 + i) = (uint8_t)(sexp + 127);
+            char *obase = reinterpret_cast<char *>(out + (int64_t)m0 * N + n0);
+#pragma unroll 2
+            for (int it = 0; it < PP_BM * (BN / 8) / 512; ++it) {
+                const int sl = it * 512 + threadIdx.x;
+                const int row = sl / (BN / 8), cp = sl % (BN / 8);   // rows past M land in the padded tail of the buffer
+                u32x4 v = lds_read_b128(stg + sl * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
+                *reinterpret_cast<u32x4 *>(obase + (int64_t)row * N * 2 + ((cp ^ (row & 15)) << 4)) = v;
+            }
+            if constexpr (!PIPE) {
+                __builtin_amdgcn_s_barrier();                 // the image is read: the slots may be refilled
+                if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
             }
         }
-        __syncthreads();
-        uint8_t *obase = out + (int64_t)m0 * N + n0;
-#pragma unroll 4
-        for (int sl = threadIdx.x; sl < PP_BM * 16; sl += 512) {
-            const int row = sl >> 4, cp = sl & 15;       // rows past M land in the padded tail of the buffer
-            *reinterpret_cast<uint4 *>(obase + (int64_t)row * N + ((cp ^ (row & 15)) << 4)) =
-                *reinterpret_cast<const uint4 *>(smem + sl * 16);
-        }
-        if (threadIdx.x < PP_BM)
-            *reinterpret_cast<uint2 *>(out_s + (int64_t)(m0 + threadIdx.x) * (N / 32) + n0 / 32) =
-                *reinterpret_cast<const uint2 *>(smem + SC0 + threadIdx.x * 8);
-    } else {
-        // acc[i][j][g]: feature n0 + wq*64 + i*32 + (g&3) + 8*(g>>2) + 4*h, token m0 + grp*128 + j*32 + r.
-        // Tile image in LDS: row = token (512 B), 16-byte slot c at c ^ (row & 15).
-        bf16_t *out = reinterpret_cast<bf16_t *>(out_);
-        auto tile_addr = [&](int row, int nloc) __attribute__((always_inline)) {
-            return smem + row * (PP_BN * 2) + (((nloc >> 3) ^ (row & 15)) << 4) + ((nloc & 4) << 1);
-        };
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int nloc = wq * 64 + i * 32 + 8 * gq + 4 * h;
-                const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + nloc);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float y0 = acc[i][j][4 * gq + 0] + bv.x, y1 = acc[i][j][4 * gq + 1] + bv.y;
-                    float y2 = acc[i][j][4 * gq + 2] + bv.z, y3 = acc[i][j][4 * gq + 3] + bv.w;
-                    if constexpr (EPI == PP_EPI_GELU) {
-                        y0 = gelu_erf(y0);
-                        y1 = gelu_erf(y1);
-                        y2 = gelu_erf(y2);
-                        y3 = gelu_erf(y3);
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2(y0, y1);
-                    o.y = pack_bf16x2(y2, y3);
-                    *reinterpret_cast<uint2 *>(tile_addr(grp * 128 + j * 32 + r, nloc)) = o;
-                }
-            }
-        __syncthreads();
-        char *obase = reinterpret_cast<char *>(out + (int64_t)m0 * N + n0);
-#pragma unroll 4
-        for (int sl = threadIdx.x; sl < PP_BM * 32; sl += 512) {
-            const int row = sl >> 5, cp = sl & 31;       // rows past M land in the padded tail of the buffer
-            *reinterpret_cast<uint4 *>(obase + (int64_t)row * N * 2 + ((cp ^ (row & 15)) << 4)) =
-                *reinterpret_cast<const uint4 *>(smem + sl * 16);
-        }
+        if (tn >= total) break;
+        t = tn;
+        m0 = m0n;
+        n0 = n0n;
     }
+    wait_vmcnt<0>();
 }
 
 // out[m, :] = LayerNorm(y[m, :] + res[m, :]) * gamma + beta, one wave per token row, fp32 statistics (two-pass).
@@ -438,26 +531,31 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const bf16_t *__restrict_
     }
 }
 
-template <int EPI, int KSEC, bool MX>
+template <int EPI, int KSEC, bool MX, int BN = 256>
 static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint8_t *ws, const float *bias, void *out,
                      uint8_t *out_s, int M, int N, int K, hipStream_t st) {
-    constexpr int lds = 2 * (PP_STAGE + (MX ? PP_SCALES : 0));
-    auto kern = gemm_pp_kernel<EPI, KSEC, MX>;
+    constexpr bool pipe_stage = EPI != PP_EPI_F32 && BN == 128;   // bf16 epilogue image beside the two slots
+    constexpr int lds = 2 * (PP_XB + BN * 128 + (MX ? PP_SCALES : 0)) + (pipe_stage ? PP_BM * BN * 2 : 0);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = gemm_pp_kernel<EPI, KSEC, MX, BN>;
     static bool attr_done = false;
     if (!attr_done) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_done = true;
     }
-    const int mtiles = (M + PP_BM - 1) / PP_BM, ntiles = N / PP_BN;
-    const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+    const int mtiles = (M + PP_BM - 1) / PP_BM, ntiles = N / BN;
+    const int total = ((mtiles + 7) / 8) * 8 * ntiles;
+    static int persist = -1;
+    if (persist < 0) { const char *e = getenv("TSIM_PP_PERSIST"); persist = e ? atoi(e) : 1; }
+    const int grid = persist && total > 256 ? 256 : total;     // one persistent workgroup per CU (a multiple of 8)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, out_s, M, N, K, mtiles, ntiles);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
 
-bool gemm_pp_supported(int N, int K) { return N % PP_BN == 0 && K % PP_BK == 0 && K >= 2 * PP_BK; }
-bool gemm_pp_mx_supported(int N, int K) { return N % PP_BN == 0 && K % 128 == 0 && K >= 256; }
+bool gemm_pp_supported(int N, int K) { return N % 128 == 0 && K % PP_BK == 0 && K >= 2 * PP_BK; }
+bool gemm_pp_mx_supported(int N, int K) { return N % 256 == 0 && K % 128 == 0 && K >= 256; }
 
 static int pp_ksec() {
     static int ksec = -1;
@@ -467,12 +565,23 @@ static int pp_ksec() {
 
 int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K,
             hipStream_t st) {
-    if (!gemm_pp_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp: N=%d K=%d not tileable by 256x64", N, K);
+    if (!gemm_pp_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp: N=%d K=%d not tileable by 128x64", N, K);
     if (M <= 0) return TSIM_OK;
     const int ksec = pp_ksec();
-#define PP_GO(E)                                                                                   \
-    return ksec == 1 ? launch_pp<E, 1, false>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)       \
-                     : launch_pp<E, 2, false>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)
+    // feature tile: 256 wide unless N is not a multiple of 256 (the 128-wide tile stages 1.5x the bytes per FLOP and
+    // measured slower on the N = 768 projections even though it fills the last round of workgroups better)
+    static int bn_env = -1;
+    if (bn_env < 0) { const char *e = getenv("TSIM_PP_BN"); bn_env = e ? atoi(e) : 0; }
+    int bn = N % 256 != 0 ? 128 : 256;
+    if (N % 256 == 0 && bn_env == 128) bn = 128;
+#define PP_GO(E)                                                                                              \
+    do {                                                                                                      \
+        if (bn == 128)                                                                                        \
+            return ksec == 1 ? launch_pp<E, 1, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st) \
+                             : launch_pp<E, 2, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st); \
+        return ksec == 1 ? launch_pp<E, 1, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)     \
+                         : launch_pp<E, 2, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st);    \
+    } while (0)
     switch (epi) {
         case PP_EPI_BIAS: PP_GO(PP_EPI_BIAS);
         case PP_EPI_GELU: PP_GO(PP_EPI_GELU);

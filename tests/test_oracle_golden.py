@@ -161,3 +161,39 @@ def test_f64_to_bf16_is_a_single_correct_rounding():
     assert (search_ref.f64_to_bf16(x) != ref).mean() < 1e-3
     u = search_ref.unit_rows(np.random.default_rng(1).standard_normal((7, 100)).astype(np.float32))
     assert np.array_equal(u, search_ref.bf16_round(u)) and abs(float((u[0].astype(np.float64) ** 2).sum()) - 1) < 2e-3
+
+
+# ---------------------------------------------------------------- MXFP8 operand format (oracle/fp8_ref.py)
+def test_fp8_oracle_e4m3_table_and_rounding_match_torch_float8():
+    """The e4m3 restatement is pinned against torch.float8_e4m3fn (an independent implementation of the OCP format):
+    the value of every byte, and round-to-nearest-even of random values, of every midpoint and of the subnormal range."""
+    import torch
+    from oracle import fp8_ref
+    vals = fp8_ref.e4m3_values()
+    t = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(np.isnan(vals), np.isnan(t))
+    np.testing.assert_array_equal(vals[~np.isnan(vals)], t[~np.isnan(t)])
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(100000) * np.exp(rng.uniform(-12, 6, 100000))).astype(np.float32)
+    fin = vals[:0x7F].astype(np.float64)
+    mid = ((fin[:-1] + fin[1:]) / 2).astype(np.float32)
+    x = np.clip(np.concatenate([x, mid, -mid, np.linspace(0, 2.0 ** -5, 4097, dtype=np.float32)]), -448, 448)
+    ref = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    np.testing.assert_array_equal(fp8_ref.f32_to_e4m3(x), ref)
+
+
+def test_fp8_oracle_mx_blocks():
+    from oracle import fp8_ref
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((5, 96)) * np.exp(rng.uniform(-8, 8, (5, 1)))).astype(np.float32)
+    x[0, :32] = 0
+    q, s = fp8_ref.mx_quantize(x)
+    assert q.shape == (5, 96) and s.shape == (5, 3) and s[0, 0] == 127 and (q[0, :32] == 0).all()
+    d = fp8_ref.mx_dequantize(q, s)
+    blk = np.abs(x.reshape(5, 3, 32)).max(-1)
+    # the block maximum lands in [256, 512) before clamping to 448: every element is within 2^-4 relative of the block max
+    assert (np.abs(d - x).reshape(5, 3, 32).max(-1) <= blk * 2.0 ** -3 + 1e-30).all()
+    # power-of-two scaling commutes with the format
+    q2, s2 = fp8_ref.mx_quantize(x * 4.0)
+    np.testing.assert_array_equal(q2, q)
+    np.testing.assert_array_equal(s2[x.reshape(5, 3, 32).any(-1)], s[x.reshape(5, 3, 32).any(-1)] + 2)

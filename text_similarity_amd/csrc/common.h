@@ -104,6 +104,37 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return fmaf(-fabsf(hx), pe, hx + fabsf(hx));
 }
 
+// GELU of two values without transcendentals, in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot).
+//   gelu(x) = x * Phi(x),  Phi(x) ~ 1/2 + xc * S(xc^2),  xc = clamp(x, -4, 4),  S = degree-8 Chebyshev fit of
+//   (Phi(sqrt u) - 1/2) / sqrt u on u in [0, 16]  (fp32 Horner: relative error <= 2.5e-5 for x > 0, absolute error
+//   <= 4e-5 on [-4, 0] — two orders below the bf16 resolution of the stored result; beyond |x| = 4 Phi is frozen at
+//   Phi(+-4) = 1 - 3.2e-5 / 3.2e-5).  26 issue cycles per value against 64 for gelu_erf (rcp + exp + 12 VALU): the FFN1
+//   epilogue is VALU-bound.  Set TSIM_GELU_ERF at build time (-DTSIM_GELU_ERF) to fall back to the A&S erf form.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void gelu2(float &a, float &b) {
+#ifdef TSIM_GELU_ERF
+    a = gelu_erf(a);
+    b = gelu_erf(b);
+#else
+    const f32x2 x = {a, b};
+    const f32x2 xc = {__builtin_amdgcn_fmed3f(a, -4.0f, 4.0f), __builtin_amdgcn_fmed3f(b, -4.0f, 4.0f)};
+    const f32x2 u = xc * xc;
+    f32x2 p = {9.56756410e-11f, 9.56756410e-11f};
+    p = __builtin_elementwise_fma(p, u, (f32x2){-8.02642397e-09f, -8.02642397e-09f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){3.00262883e-07f, 3.00262883e-07f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){-6.72069427e-06f, -6.72069427e-06f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){1.02510894e-04f, 1.02510894e-04f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){-1.15122017e-03f, -1.15122017e-03f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){9.92152281e-03f, 9.92152281e-03f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){-6.64609522e-02f, -6.64609522e-02f});
+    p = __builtin_elementwise_fma(p, u, (f32x2){3.98939520e-01f, 3.98939520e-01f});
+    const f32x2 phi = __builtin_elementwise_fma(xc, p, (f32x2){0.5f, 0.5f});
+    const f32x2 y = x * phi;
+    a = y[0];
+    b = y[1];
+#endif
+}
+
 // async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,

@@ -331,10 +331,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                     float y0 = acc[i][j][4 * gq + 0], y1 = acc[i][j][4 * gq + 1];
                     float y2 = acc[i][j][4 * gq + 2], y3 = acc[i][j][4 * gq + 3];
                     if constexpr (EPI == EPI_GELU) {
-                        y0 = gelu_erf(y0);
-                        y1 = gelu_erf(y1);
-                        y2 = gelu_erf(y2);
-                        y3 = gelu_erf(y3);
+                        gelu2(y0, y1);
+                        gelu2(y2, y3);
                     }
                     uint2 o;
                     o.x = pack_bf16x2(y0, y1);
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                         float y0 = acc[i][4 * gq] + bv.x, y1 = acc[i][4 * gq + 1] + bv.y;
                         float y2 = acc[i][4 * gq + 2] + bv.z, y3 = acc[i][4 * gq + 3] + bv.w;
                         if constexpr (EPI == EPI_GELU) {
-                            y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
+                            gelu2(y0, y1); gelu2(y2, y3);
                         }
                         pk[2 * gq] = pack_bf16x2(y0, y1);
                         pk[2 * gq + 1] = pack_bf16x2(y2, y3);
@@ -510,7 +508,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                             float y0 = acc[i][4 * gq] + bv.x, y1 = acc[i][4 * gq + 1] + bv.y;
                             float y2 = acc[i][4 * gq + 2] + bv.z, y3 = acc[i][4 * gq + 3] + bv.w;
                             if constexpr (EPI == EPI_GELU) {
-                                y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3);
+                                gelu2(y0, y1); gelu2(y2, y3);
                             }
                             pk[2 * gq] = pack_bf16x2(y0, y1);
                             pk[2 * gq + 1] = pack_bf16x2(y2, y3);

@@ -350,10 +350,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                     float amax = 0.f;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        y[4 * gq + 0] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 0] + bv[gq].x));
-                        y[4 * gq + 1] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 1] + bv[gq].y));
-                        y[4 * gq + 2] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 2] + bv[gq].z));
-                        y[4 * gq + 3] = bf16_round_f32(gelu_erf(acc[i][j][4 * gq + 3] + bv[gq].w));
+                        float t0 = acc[i][j][4 * gq + 0] + bv[gq].x, t1 = acc[i][j][4 * gq + 1] + bv[gq].y;
+                        float t2 = acc[i][j][4 * gq + 2] + bv[gq].z, t3 = acc[i][j][4 * gq + 3] + bv[gq].w;
+                        gelu2(t0, t1);
+                        gelu2(t2, t3);
+                        y[4 * gq + 0] = bf16_round_f32(t0);
+                        y[4 * gq + 1] = bf16_round_f32(t1);
+                        y[4 * gq + 2] = bf16_round_f32(t2);
+                        y[4 * gq + 3] = bf16_round_f32(t3);
                     }
 #pragma unroll
                     for (int g = 0; g < 16; ++g) amax = fmaxf(amax, fabsf(y[g]));
@@ -414,10 +418,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                         float y0 = acc[i][j][4 * gq + 0] + bv[0], y1 = acc[i][j][4 * gq + 1] + bv[1];
                         float y2 = acc[i][j][4 * gq + 2] + bv[2], y3 = acc[i][j][4 * gq + 3] + bv[3];
                         if constexpr (EPI == PP_EPI_GELU) {
-                            y0 = gelu_erf(y0);
-                            y1 = gelu_erf(y1);
-                            y2 = gelu_erf(y2);
-                            y3 = gelu_erf(y3);
+                            gelu2(y0, y1);
+                            gelu2(y2, y3);
                         }
                         const uint64_t o = (uint64_t)pack_bf16x2(y0, y1) | ((uint64_t)pack_bf16x2(y2, y3) << 32);
                         const int row = grp * 128 + j * 32 + r;

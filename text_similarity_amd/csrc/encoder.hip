@@ -96,7 +96,7 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int NST = 2
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
     const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles, int diag) {
+    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MT = TM / 32, NT = TN / 32;
     constexpr int RB = BK * 2;       // bytes per tile row
@@ -171,33 +171,58 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         for (int i = 0; i < NST - 1; ++i) issue(i < nk ? i : nk - 1, i);   // past-the-end: re-read (uniform vmcnt)
     }
     for (int kt = 0; kt < nk; ++kt) {
-        if constexpr (NST == 2) {
-            wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();   // tile kt landed for everyone; everyone finished reading tile kt-1
-            if (kt + 1 < nk && !(diag & 4)) issue(kt + 1, (kt + 1) & 1);   // diag 4: DIAGNOSTIC, no staging after tile 0
-        } else {
-            wait_vmcnt<(NST - 2) * PPW>();  // tile kt landed (NST-2 younger tiles may be in flight)
-            __builtin_amdgcn_s_barrier();
-            const int nx = kt + NST - 1;
-            issue(nx < nk ? nx : nk - 1, nx % NST);
-        }
         const char *xs = smem + (kt % NST) * STAGE;
         const char *ws = xs + X_BYTES;
-        if (diag & 2) continue;             // DIAGNOSTIC: staging and barriers only, no fragment reads / MFMA
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            bf16x8 bx[MT], aw[NT];
+        auto load_frags = [&](int s, bf16x8 (&bx)[MT], bf16x8 (&aw)[NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 bx[j] = *reinterpret_cast<const bf16x8 *>(xs + frag_off(wm * TM + j * 32 + r, s));
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 aw[i] = *reinterpret_cast<const bf16x8 *>(ws + frag_off(wn * TN + i * 32 + r, s));
+        };
+        if constexpr (NST == 2) {
+            // tile kt landed for everyone; everyone finished reading tile kt-1.  The next tile's DMA pieces are issued
+            // a k-step's worth at a time BEHIND that k-step's MFMAs (a piece costs its wave ~100 issue cycles: all of
+            // them up front would leave the matrix pipe idle), and the fragments of k-step s+1 are read before the
+            // MFMAs of k-step s.
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            bf16x8 bx[2][MT], aw[2][NT];
+            load_frags(0, bx[0], aw[0]);
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) load_frags(s + 1, bx[(s + 1) & 1], aw[(s + 1) & 1]);
+                if (kt + 1 < nk) {
 #pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[i], bx[j], acc[i][j], 0, 0, 0);
+                    for (int i = s * PPW_MAX / KSTEPS; i < (s + 1) * PPW_MAX / KSTEPS; ++i) {
+                        const int p = wave + i * NW;
+                        if (p < PIECES)
+                            glds16((p < XPIECES ? xbase : wbase) + src_off[i] + (kt + 1) * (BK * 2),
+                                   smem + ((kt + 1) & 1) * STAGE + p * 1024);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[s & 1][i], bx[s & 1][j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            wait_vmcnt<(NST - 2) * PPW>();  // tile kt landed (NST-2 younger tiles may be in flight)
+            __builtin_amdgcn_s_barrier();
+            const int nx = kt + NST - 1;
+            issue(nx < nk ? nx : nk - 1, nx % NST);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                bf16x8 bx[MT], aw[NT];
+                load_frags(s, bx, aw);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[i], bx[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -314,7 +339,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
             char *obase = reinterpret_cast<char *>(out + (int64_t)m0 * N);
             for (int sl = threadIdx.x; sl < BM * SPR; sl += NW * 64) {
                 const int row = sl / SPR, cp = sl % SPR;
-                if ((diag & 1) == 0 && m0 + row < M)
+                if (m0 + row < M)
                     *reinterpret_cast<uint4 *>(obase + (int64_t)row * (BN * 2) + ((cp ^ (row & SWZ)) << 4)) =
                         *reinterpret_cast<const uint4 *>(smem + sl * 16);
             }
@@ -337,8 +362,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                     uint2 o;
                     o.x = pack_bf16x2(y0, y1);
                     o.y = pack_bf16x2(y2, y3);
-                    if (diag & 1) asm volatile("" ::"v"(o.x), "v"(o.y));   // DIAGNOSTIC: no stores
-                    else *reinterpret_cast<uint2 *>(out + m * N + n) = o;
+                    *reinterpret_cast<uint2 *>(out + m * N + n) = o;
                 }
             }
     }
@@ -870,10 +894,8 @@ static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, cons
     if (N % BN != 0 || K % BK != 0) return fail(TSIM_EUNSUPPORTED, "gemm: N=%d K=%d not tileable by %dx%d", N, K, BN, BK);
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    static int diag = -1;
-    if (diag < 0) { const char *e = getenv("TSIM_GEMM_DIAG"); diag = e ? atoi(e) : 0; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, X, W, bias, res, gamma, beta, eps, out, M, N, K,
-                       mtiles, ntiles, diag);
+                       mtiles, ntiles);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -898,10 +920,7 @@ static int gemm_xres_nw(const bf16_t *X, const bf16_t *W, const float *bias, bf1
 
 template <int EPI>
 static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
-    static int nw = -1;
-    if (nw < 0) { const char *e = getenv("TSIM_XRES_WAVES"); nw = e ? atoi(e) : 8; }
-    if (nw == 4) return gemm_xres_nw<EPI, 4>(X, W, bias, out, M, N, st);
-    return gemm_xres_nw<EPI, 8>(X, W, bias, out, M, N, st);
+    return gemm_xres_nw<EPI, 8>(X, W, bias, out, M, N, st);   // 8 waves = 256 tokens per workgroup (4-wave groups measured slower)
 }
 
 template <int EPI>

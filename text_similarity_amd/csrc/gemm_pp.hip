@@ -16,8 +16,10 @@
 // before the closing barrier; every wave waits vmcnt(0) for its pieces of t+1 in the last interval of tile t, one
 // barrier before group 0's first read of it.  All LDS traffic inside the loop is inline asm so that hipcc neither
 // drains the DMA (s_waitcnt vmcnt(0)) before "aliasing" LDS reads nor re-schedules loads across the raw s_barrier.
-// Roofline: MFMA.  Per k-tile a workgroup stages 64 KiB for 4.2 MFLOP... = 128 FLOP/B from L2, 16 B/clk/CU at full
-// MFMA rate (measured LDS-DMA ceiling: 40-56 B/clk/CU).
+// Roofline: MFMA.  Per k-tile a workgroup stages 64 KiB for 8.4 MFLOP = 128 FLOP/B from L2: 32 B/clk/CU at the full
+// MFMA rate (32 cycles per 32x32x16 MFMA), against a measured LDS-DMA ceiling of 40-56 B/clk/CU.
+// Persistent workgroups walk the tile list with stride gridDim.x; where the epilogue has LDS of its own (fp32 output, or
+// 128-wide feature tiles) the next tile's first k-tile is fetched during the epilogue.
 //
 // Epilogues: bias | bias + GELU(erf) -> bf16, staged through LDS so that every global store is a 16-byte piece of a
 // 512-byte row segment;  bias -> fp32 (pre-LayerNorm sums; the MFMA operands are swapped so that the feature runs

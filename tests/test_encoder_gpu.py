@@ -198,3 +198,27 @@ def test_from_pretrained_local_directory(tmp_path):
         from text_similarity_amd.dataset.dataset import EmbeddingsFeatures
         out = m.encode(EmbeddingsFeatures(ids, mask))
         assert np.abs(out.cpu().numpy() - g["pooled"]).max() <= POOL_TOL
+
+
+@pytest.mark.parametrize("preset,wdtype", [("bert-base-uncased", "bf16"), ("bert-base-uncased", "mxfp8"),
+                                           ("all-mpnet-base-v2", "bf16"), ("all-MiniLM-L6-v2", "bf16")])
+def test_large_batch_equals_small_batches_bitwise(preset, wdtype):
+    """~24 k tokens in one call: every projection launch has more output tiles than CUs, so the persistent workgroups of
+    the ping-pong kernel walk several tiles each (next tile's first k-tile fetched during the epilogue, slot parity and
+    source offsets carried across tiles) and the LayerNorm GEMMs take their main + tail launches.  Rows are independent
+    and every kernel sums over k in the same order whatever the tile, so the result must equal — bit for bit — the same
+    sentences encoded 48 at a time (one tile per workgroup, no tail)."""
+    cfg = presets.PRESETS[preset]
+    n = 2300 if cfg.hidden == 384 else 1500          # MiniLM: > 32768 tokens, so the LayerNorm GEMMs split main + tail
+    flat, cu = presets.synthetic_token_batch(n, seed="big/" + preset, vocab_size=cfg.vocab, max_len=64)
+    cu = cu.astype(np.int64)
+    enc = NativeEncoder.from_preset(preset, max_tokens=int(cu[-1]), max_seqs=n, weight_dtype=wdtype)
+    big = enc.forward_packed(torch.from_numpy(flat).to(DEV), torch.from_numpy(cu.astype(np.int32)).to(DEV))["pooled"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(big).all()
+    for s in (0, 480, 1452):
+        rows = slice(s, s + 48)
+        f = flat[cu[s]:cu[s + 48]]
+        c = (cu[s:s + 49] - cu[s]).astype(np.int32)
+        small = enc.forward_packed(torch.from_numpy(f).to(DEV), torch.from_numpy(c).to(DEV))["pooled"]
+        assert torch.equal(small, big[rows]), f"{preset}/{wdtype}: rows {s}.. differ between batch sizes"

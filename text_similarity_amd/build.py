@@ -88,5 +88,6 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    # --stamps: DIAGNOSTIC build of the ping-pong GEMM with in-kernel cycle stamps (tools/pp_stamps.py); rebuild without it after
+    build(force="--force" in sys.argv or "--stamps" in sys.argv, extra_flags=["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else ())
     print(LIB)

@@ -770,7 +770,8 @@ struct tsim_encoder {
     int relw = 0;
     struct Layer {
         bf16_t *wqkv, *wo, *w1, *w2;
-        uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes ...
+        bf16_t *pqkv = nullptr, *po = nullptr, *p1 = nullptr, *p2 = nullptr;     // tile-major copies for the ping-pong GEMM
+        uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes (tile-major) ...
         uint8_t *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // ... and E8M0 block scales [out, in/32]
         float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
     };
@@ -924,27 +925,28 @@ static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t
 }
 
 template <int EPI>
-static int gemm_plain(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, int K,
-                      hipStream_t st) {
+static int gemm_plain(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, bf16_t *out, int M, int N,
+                      int K, hipStream_t st) {
     static int use_xres = -1, big = -1;
     if (use_xres < 0) { const char *e = getenv("TSIM_GEMM_XRES"); use_xres = e ? atoi(e) : 1; }
     if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
     if (use_xres && big != 2 && K == 384 && N % XR_BN == 0) return gemm_xres<EPI>(X, W, bias, out, M, N, st);
     if (big && (K >= 768 || big == 2) && gemm_pp_supported(N, K))
-        return gemm_pp(EPI == EPI_GELU ? PP_EPI_GELU : PP_EPI_BIAS, X, W, bias, out, M, N, K, st);
+        return gemm_pp(EPI == EPI_GELU ? PP_EPI_GELU : PP_EPI_BIAS, X, Wp ? Wp : W, Wp != nullptr, bias, out, M, N, K, st);
     if (N % 128 == 0)
         return launch_gemm<128, 128, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
     return launch_gemm<128, 64, 64, 2, 2, EPI>(X, W, bias, nullptr, nullptr, nullptr, 0.f, out, M, N, K, st);
 }
 
-static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
-                       const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf, hipStream_t st) {
+static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, const bf16_t *res,
+                       const float *gamma, const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf,
+                       hipStream_t st) {
     static int big = -1;
     if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
     if (big && ybuf && N >= 512 && N % 256 == 0 && gemm_pp_supported(N, K)) {
         // wide rows: a workgroup cannot own whole 768-feature rows at a 256-token tile, so the projection writes
         // fp32 sums and a row kernel adds the residual and normalises (HBM-bound, 8 B per element)
-        int rc = gemm_pp(PP_EPI_F32, X, W, bias, ybuf, M, N, K, st);
+        int rc = gemm_pp(PP_EPI_F32, X, Wp ? Wp : W, Wp != nullptr, bias, ybuf, M, N, K, st);
         if (rc) return rc;
         return res_ln_rows(ybuf, res, gamma, beta, eps, out, nullptr, nullptr, M, N, st);
     }
@@ -1026,6 +1028,23 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
             if ((rc = upload_mxfp8(e, {lw.w1}, F, H, &d.q1, &d.s1))) return bail(rc);
             if ((rc = upload_mxfp8(e, {lw.w2}, H, F, &d.q2, &d.s2))) return bail(rc);
         }
+        // tile-major copies for the ping-pong projections (contiguous 1-KiB DMA pieces): [feature tile][k-tile][LDS image]
+        auto repack = [&](const void *src, int n_rows, int kbytes, void **dst) {
+            int r2 = dev_alloc(e, (size_t)n_rows * kbytes, dst);
+            return r2 ? r2 : pack_w(src, *dst, n_rows, kbytes, gemm_pp_tile_width(n_rows), nullptr);
+        };
+        if (mx) {
+            void *t;
+            if ((rc = repack(d.qqkv, 3 * H, H, &t))) return bail(rc); d.qqkv = (uint8_t *)t;
+            if ((rc = repack(d.qo, H, H, &t))) return bail(rc); d.qo = (uint8_t *)t;
+            if ((rc = repack(d.q1, F, H, &t))) return bail(rc); d.q1 = (uint8_t *)t;
+            if ((rc = repack(d.q2, H, F, &t))) return bail(rc); d.q2 = (uint8_t *)t;
+        } else if (H >= 512 && H % 256 == 0 && gemm_pp_supported(H, H) && gemm_pp_supported(F, H) && gemm_pp_supported(H, F)) {
+            if ((rc = repack(d.wqkv, 3 * H, H * 2, (void **)&d.pqkv))) return bail(rc);
+            if ((rc = repack(d.wo, H, H * 2, (void **)&d.po))) return bail(rc);
+            if ((rc = repack(d.w1, F, H * 2, (void **)&d.p1))) return bail(rc);
+            if ((rc = repack(d.w2, H, F * 2, (void **)&d.p2))) return bail(rc);
+        }
         std::vector<float> bq(3 * (size_t)H);
         memcpy(bq.data(), lw.bq, H * 4);
         memcpy(bq.data() + H, lw.bk, H * 4);
@@ -1074,7 +1093,7 @@ extern "C" int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, c
     TSIM_REQUIRE(xq && xs && wq && ws && bias && out_f32, "gemm_mxfp8: null pointer");
     TSIM_REQUIRE(M >= 0 && N > 0 && K > 0, "gemm_mxfp8: bad shape M=%d N=%d K=%d", M, N, K);
     return gemm_pp_mx(PP_EPI_F32, static_cast<const uint8_t *>(xq), static_cast<const uint8_t *>(xs),
-                      static_cast<const uint8_t *>(wq), static_cast<const uint8_t *>(ws), bias, out_f32, nullptr, M, N, K,
+                      static_cast<const uint8_t *>(wq), 0, static_cast<const uint8_t *>(ws), bias, out_f32, nullptr, M, N, K,
                       reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1115,8 +1134,8 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
             if (mx) {   // projections on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4); x0's image comes fused from the
                         // previous layer's LayerNorm kernel, for layer 0 from the stand-alone quantiser
                 if (l == 0 && (rc = quant_mx(e->x0, T, H, e->aq, e->as, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, L.sqkv, L.bqkv, e->qkv, nullptr, T, 3 * H, H, st))) return rc;
-            } else if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, 1, L.sqkv, L.bqkv, e->qkv, nullptr, T, 3 * H, H, st))) return rc;
+            } else if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.pqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
 #define ATT(D)                                                                                                 \
     do {                                                                                                       \
         if (rel)                                                                                               \
@@ -1131,16 +1150,16 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
             TSIM_HIP_CHECK(hipGetLastError());
             if (mx) {
                 if ((rc = quant_mx(e->ctx, T, H, e->aq, e->as, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_F32, e->aq, e->as, L.qo, L.so, L.bo, e->ybuf, nullptr, T, H, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->aq, e->as, L.qo, 1, L.so, L.bo, e->ybuf, nullptr, T, H, H, st))) return rc;
                 if ((rc = res_ln_rows(e->ybuf, e->x0, L.g1, L.be1, c.ln_eps, e->x1, e->aq, e->as, T, H, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_GELU_MX, e->aq, e->as, L.q1, L.s1, L.b1, e->hq, e->hs, T, F, H, st))) return rc;
-                if ((rc = gemm_pp_mx(PP_EPI_F32, e->hq, e->hs, L.q2, L.s2, L.b2, e->ybuf, nullptr, T, H, F, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_GELU_MX, e->aq, e->as, L.q1, 1, L.s1, L.b1, e->hq, e->hs, T, F, H, st))) return rc;
+                if ((rc = gemm_pp_mx(PP_EPI_F32, e->hq, e->hs, L.q2, 1, L.s2, L.b2, e->ybuf, nullptr, T, H, F, st))) return rc;
                 if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, e->aq, e->as, T, H, st))) return rc;
                 continue;
             }
-            if ((rc = gemm_res_ln(e->ctx, L.wo, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
-            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
+            if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
+            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.p1, L.b1, e->h1, T, F, H, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, L.p2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

@@ -77,12 +77,24 @@ __device__ __forceinline__ float bf16_round_f32(float f) { return __uint_as_floa
 // of that instruction, pinned on hardware by tools/microbench/mx_layout.hip: lane (r, h) holds row r, bytes 0-15 of its
 // 8 VGPRs = k 16h..16h+15 (scale block 0), bytes 16-31 = k 32+16h.. (scale block 1); the scale byte a lane supplies
 // (selected by opsel) belongs to block h of its row.
+#ifdef TSIM_PP_STAMPS
+// DIAGNOSTIC build only (python -m text_similarity_amd.build --stamps): wave 0 of every workgroup accumulates where a
+// tile's cycles go.  [0] tiles, [1] wait for the first k-tile + top barriers, [2] k loop, [3] epilogue, [4] MFMA sections,
+// [5] load sections, [6] barrier waits, [7] wait for the next k-tile's DMA (vmcnt).
+__device__ unsigned long long g_pp_stamps[8];
+#define PP_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PP_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_pp_stamps[i], (unsigned long long)(v)); } while (0)
+#else
+#define PP_STAMP(var) do { } while (0)
+#define PP_ACC(i, v) do { } while (0)
+#endif
+
 template <int EPI, int KSEC, bool MX, int BN>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X_, const void *__restrict__ W_,
                                                       const uint8_t *__restrict__ xs, const uint8_t *__restrict__ ws,
                                                       const float *__restrict__ bias, void *__restrict__ out_,
                                                       uint8_t *__restrict__ out_s, int M, int N, int K, int mtiles,
-                                                      int ntiles) {
+                                                      int ntiles, int wpk) {
     constexpr int ESZ = MX ? 1 : 2;                  // bytes per element
     constexpr int NSTEP = MX ? 2 : 4;                // MFMA k-steps per k-tile
     constexpr int NSEC = NSTEP / KSEC;
@@ -121,15 +133,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
     // super-row sr stored at chunk c ^ (sr & 15): the 32 rows x 2 k-halves of a ds_read_b128 fragment hit 16 distinct
     // chunks per 16 lanes (conflict-free).  Piece p = 1 KiB = 64 lanes x 16 B, LDS-linear.
     // DMA sources: wave-uniform operand base (SGPRs) + one 32-bit byte offset per piece, advanced by 128 per k-tile.
+    // wpk: W was re-laid at load time as [feature tile][k-tile][LDS image of the tile] (pack_w_kernel), so a W piece is
+    // 1 KiB of CONTIGUOUS memory instead of 8 row segments of 128 B: LDS-DMA moves contiguous pieces about twice as fast,
+    // and the staging rate, not the matrix pipe, bounds this kernel.
     uint32_t src_off[PP_PPW];
-    uint32_t advanced = 0;                                // bytes the offsets have moved since they were set
+    uint32_t advanced = 0;                                // k-tiles the offsets have moved since they were set
+    const uint32_t wstep = wpk ? BN * 128 : 128;          // bytes per k-tile on the W side
 #pragma unroll
     for (int i = 0; i < PP_PPW; ++i) {
         const int p = wave + i * 8;                       // < 32: X piece, else W piece
         const int sl = (p & 31) * 64 + lane;
         const int sr = sl >> 4, chp = sl & 15;
         const int ch = chp ^ (sr & 15);
-        src_off[i] = (uint32_t)((sr * 2 + (ch >> 3)) * K * ESZ + (ch & 7) * 16);
+        src_off[i] = (i >= 4 && wpk) ? (uint32_t)((p - 32) * 1024 + lane * 16)
+                                     : (uint32_t)((sr * 2 + (ch >> 3)) * K * ESZ + (ch & 7) * 16);
     }
     const char *xbase = nullptr, *wbase = nullptr;
     // MXFP8 scales of a k-tile: one dword (4 blocks) per row; wave w < 4 brings token rows 64w.., wave w >= 4 feature rows
@@ -137,9 +154,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
     uint32_t sc_off = 0;
     auto set_sources = [&](int m0, int n0) __attribute__((always_inline)) {
         xbase = reinterpret_cast<const char *>(X_) + (int64_t)m0 * K * ESZ;
-        wbase = reinterpret_cast<const char *>(W_) + (int64_t)n0 * K * ESZ;
+        wbase = reinterpret_cast<const char *>(W_) + (int64_t)n0 * K * ESZ;   // packed or not: a feature tile's data starts here
 #pragma unroll
-        for (int i = 0; i < PP_PPW; ++i) src_off[i] -= advanced;
+        for (int i = 0; i < PP_PPW; ++i) src_off[i] -= advanced * (i < 4 ? 128u : wstep);
         advanced = 0;
         if constexpr (MX) {
             sc_base = wave < 4 ? xs + (int64_t)(m0 + wave * 64) * (K / 32) : ws + (int64_t)(n0 + (wave - 4) * 64) * (K / 32);
@@ -151,9 +168,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
         for (int i = 0; i < PP_PPW; ++i) {
             const int p = wave + i * 8;
             glds16((i < 4 ? xbase : wbase) + (size_t)src_off[i], smem + slot * STAGE + p * 1024);
-            src_off[i] += 128;
+            src_off[i] += i < 4 ? 128u : wstep;
         }
-        advanced += 128;
+        advanced += 1;
         if constexpr (MX) {
             glds4(sc_base + (size_t)sc_off, smem + slot * STAGE + PP_STAGE + wave * 256);
             sc_off += 4;
@@ -173,16 +190,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
     const uint32_t wsoff0 = PP_STAGE + 1024 + (wq * WFEAT + r) * 4;
 
     const int nk = K * ESZ / 128;
-    // Epilogue staging: when it has LDS of its own (PIPE) the next tile's first k-tile is fetched DURING the epilogue.
-    constexpr bool PIPE = F32 || BN == 128;
-    constexpr int STG = PIPE ? 2 * STAGE : 0;
+    // The next tile's first k-tile is fetched DURING the epilogue, into the slot its parity selects; the epilogue stages its
+    // output image (row-contiguous global stores) through the OTHER slot, 64 KiB at a time.  Without this a workgroup sits
+    // idle while its stores drain (vmcnt is in order) and then again for the first DMA of the next tile: ~8 of 25 us per
+    // tile on the K = 768 projections.
+    constexpr bool PIPE = true;
     int t = blockIdx.x, m0, n0;
     if (!tile_at(t, m0, n0)) t = next_tile(t);
     if (t >= total) return;
     (void)tile_at(t, m0, n0);
     set_sources(m0, n0);
     uint32_t kidx = 0;                                    // k-tiles consumed so far: slot parity across tiles
-    constexpr int EPI_STORES = F32 ? NI * 64 : PP_BM * (BN / 8) / 512;   // global stores per wave in one epilogue
+    constexpr int EPI_STORES = F32 ? NI * 64 : (EPI == PP_EPI_GELU_MX ? 9 : PP_BM * (BN / 8) / 512);   // global stores per wave in one epilogue
     bool first = true;
     issue(0);
     for (;;) {
@@ -195,10 +214,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                 for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
         // my pieces of this tile's first k-tile have landed.  They are OLDER than the previous epilogue's global stores
         // when the fetch was issued ahead of them (PIPE): leave those stores in flight (vmcnt is in order, 6 bits wide)
+        PP_STAMP(ts0);
         if (first || !PIPE) wait_vmcnt<0>(); else wait_vmcnt<(EPI_STORES < 63 ? EPI_STORES : 63)>();
         first = false;
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one interval behind group 0
+        PP_STAMP(ts1);
+#ifdef TSIM_PP_STAMPS
+        unsigned long long msum = 0, lsum = 0, b1sum = 0, b2sum = 0, dsum = 0, tprev = 0;
+#endif
 
         for (int kt = 0; kt < nk; ++kt) {
             const uint32_t sbase = lds0 + ((kidx + kt) & 1) * STAGE;
@@ -206,6 +230,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
 #pragma unroll
             for (int sec = 0; sec < NSEC; ++sec) {
                 // ---------------- L: fragments of KSEC k-steps (+ the next k-tile's DMA)
+#ifdef TSIM_PP_STAMPS
+                const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+                if (tprev) b2sum += tl0 - tprev;
+#endif
                 u32x4 xf[KSEC][4], wf[KSEC][NI], xg[KSEC][4], wg[KSEC][NI];   // xg/wg: second 16 bytes of an MXFP8 fragment
 #pragma unroll
                 for (int ks = 0; ks < KSEC; ++ks) {
@@ -263,10 +291,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                         for (int j = 0; j < 4; ++j) xsv[j] >>= 8 * h;
                     }
                 }
+#ifdef TSIM_PP_STAMPS
+                const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
+                lsum += tl1 - tl0;
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---------------- M
+                PP_STAMP(tm0);
+#ifdef TSIM_PP_STAMPS
+                b1sum += tm0 - tl1;
+#endif
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < KSEC; ++ks)
@@ -301,13 +337,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]));
                 if constexpr (NI == 2) asm volatile("" : "+v"(acc[NI - 1][0]), "+v"(acc[NI - 1][1]), "+v"(acc[NI - 1][2]), "+v"(acc[NI - 1][3]));
                 __builtin_amdgcn_s_setprio(0);
+#ifdef TSIM_PP_STAMPS
+                tprev = __builtin_amdgcn_s_memtime();
+                msum += tprev - tm0;
+#endif
                 if (sec == NSEC - 1 && grp == 0) wait_vmcnt<0>();
+#ifdef TSIM_PP_STAMPS
+                if (sec == NSEC - 1) { const unsigned long long tw = __builtin_amdgcn_s_memtime(); dsum += tw - tprev; tprev = tw; }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's last barrier: everyone is done with LDS
+        PP_STAMP(ts2);
         kidx += nk;
         const int tn = next_tile(t);
         int m0n = 0, n0n = 0;
@@ -338,22 +382,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
         } else if constexpr (EPI == PP_EPI_GELU_MX) {
             // bias + GELU, rounded to bf16 (what the unfused path stores), then straight to MXFP8 — the next projection's
             // operand format: the 32 features i*32.. of a token are one scale block, 16 values in lane (r, 0) and 16 in
-            // lane (r, 1).  Bytes and scales go through LDS so that global stores are row-contiguous.
+            // lane (r, 1).  Bytes (64 KiB) and scales (2 KiB) are staged in the slot the prefetch does not use.
             uint8_t *out = reinterpret_cast<uint8_t *>(out_);
             constexpr int SC0 = PP_BM * BN;               // scale image [256 tokens][8 blocks] behind the byte image
+            u32x4 bvr[NI][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    asm volatile("global_load_dwordx4 %0, %1, off"
+                                 : "=v"(bvr[i][gq]) : "v"(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h) : "memory");
+            if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+            if (tn < total) wait_vmcnt<PP_PPW + 1>(); else wait_vmcnt<0>();   // the bias loads are older than the DMA
+#pragma unroll
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bvr[i][0]), "+v"(bvr[i][1]), "+v"(bvr[i][2]), "+v"(bvr[i][3]));
+            const uint32_t stg = lds0 + ((kidx & 1) ^ 1) * STAGE;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                float4 bv[4];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) bv[gq] = *reinterpret_cast<const float4 *>(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float y[16];
                     float amax = 0.f;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        float t0 = acc[i][j][4 * gq + 0] + bv[gq].x, t1 = acc[i][j][4 * gq + 1] + bv[gq].y;
-                        float t2 = acc[i][j][4 * gq + 2] + bv[gq].z, t3 = acc[i][j][4 * gq + 3] + bv[gq].w;
+                        const f32x4 bv = __builtin_bit_cast(f32x4, bvr[i][gq]);
+                        float t0 = acc[i][j][4 * gq + 0] + bv[0], t1 = acc[i][j][4 * gq + 1] + bv[1];
+                        float t2 = acc[i][j][4 * gq + 2] + bv[2], t3 = acc[i][j][4 * gq + 3] + bv[3];
                         gelu2(t0, t1);
                         gelu2(t2, t3);
                         y[4 * gq + 0] = bf16_round_f32(t0);
@@ -369,52 +423,60 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int nloc = wq * WFEAT + i * 32 + 8 * gq + 4 * h;
-                        *reinterpret_cast<uint32_t *>(smem + row * BN + (((nloc >> 4) ^ (row & 15)) << 4) + (nloc & 15)) =
-                            mx_pack4(y[4 * gq], y[4 * gq + 1], y[4 * gq + 2], y[4 * gq + 3], sexp);
+                        const uint32_t ad = stg + row * BN + (((nloc >> 4) ^ (row & 15)) << 4) + (nloc & 15);
+                        const uint32_t pk = mx_pack4(y[4 * gq], y[4 * gq + 1], y[4 * gq + 2], y[4 * gq + 3], sexp);
+                        asm volatile("ds_write_b32 %0, %1" ::"v"(ad), "v"(pk) : "memory");
                     }
-                    if (h == 0) *reinterpret_cast<uint8_t *>(smem + SC0 + row * 8 + wq * NI + i) = (uint8_t)(sexp + 127);
+                    if (h == 0) {
+                        const uint32_t ad = stg + SC0 + row * 8 + wq * NI + i;
+                        const uint32_t sb = (uint32_t)(sexp + 127);
+                        asm volatile("ds_write_b8 %0, %1" ::"v"(ad), "v"(sb) : "memory");
+                    }
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             uint8_t *obase = out + (int64_t)m0 * N + n0;
-#pragma unroll 4
-            for (int sl = threadIdx.x; sl < PP_BM * 16; sl += 512) {
+#pragma unroll 2
+            for (int it = 0; it < PP_BM * 16 / 512; ++it) {
+                const int sl = it * 512 + threadIdx.x;
                 const int row = sl >> 4, cp = sl & 15;       // rows past M land in the padded tail of the buffer
-                *reinterpret_cast<uint4 *>(obase + (int64_t)row * N + ((cp ^ (row & 15)) << 4)) =
-                    *reinterpret_cast<const uint4 *>(smem + sl * 16);
+                u32x4 v = lds_read_b128_o<0>(stg + sl * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
+                *reinterpret_cast<u32x4 *>(obase + (int64_t)row * N + ((cp ^ (row & 15)) << 4)) = v;
             }
-            if (threadIdx.x < PP_BM)
-                *reinterpret_cast<uint2 *>(out_s + (int64_t)(m0 + threadIdx.x) * (N / 32) + n0 / 32) =
-                    *reinterpret_cast<const uint2 *>(smem + SC0 + threadIdx.x * 8);
-            __syncthreads();                                  // the image is read: the slots may be refilled
-            if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+            {
+                const int row = threadIdx.x >> 1, half = threadIdx.x & 1;   // 256 rows x 8 scale bytes, 4 per thread
+                uint32_t v = lds_read_b32_o<0>(stg + SC0 + row * 8 + half * 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
+                *reinterpret_cast<uint32_t *>(out_s + (int64_t)(m0 + row) * (N / 32) + n0 / 32 + half * 4) = v;
+            }
         } else {
             // acc[i][j][g]: feature n0 + wq*WFEAT + i*32 + (g&3) + 8*(g>>2) + 4*h, token m0 + grp*128 + j*32 + r.
-            // Tile image in LDS (at STG): row = token (BN*2 bytes), 16-byte slot c at c ^ (row & 15).  LDS traffic by inline
-            // asm and raw barriers, bias by asm loads issued BEFORE the prefetch DMA: nothing here drains that DMA.
+            // Output image in LDS (the slot the prefetch does not use): row = token (BN*2 bytes), 16-byte slot c at
+            // c ^ (row & 15); one pass per wave group = token half (128 rows: 64 KiB of a 256-wide tile, 32 KiB of a 128-wide one).
+            // LDS traffic by inline asm and raw barriers, bias by asm loads issued BEFORE the prefetch DMA: nothing here
+            // drains that DMA.
             bf16_t *out = reinterpret_cast<bf16_t *>(out_);
-            u32x4 bvr[PIPE ? NI : 1][4];
-            if constexpr (PIPE) {
+            constexpr int NPASS = 2, ROWS = 128;
+            u32x4 bvr[NI][4];
 #pragma unroll
-                for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        asm volatile("global_load_dwordx4 %0, %1, off"
-                                     : "=v"(bvr[i][gq]) : "v"(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h) : "memory");
-                if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
-                if (tn < total) wait_vmcnt<PP_PPW + (MX ? 1 : 0)>(); else wait_vmcnt<0>();   // the bias loads are older
+                for (int gq = 0; gq < 4; ++gq)
+                    asm volatile("global_load_dwordx4 %0, %1, off"
+                                 : "=v"(bvr[i][gq]) : "v"(bias + n0 + wq * WFEAT + i * 32 + 8 * gq + 4 * h) : "memory");
+            if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+            if (tn < total) wait_vmcnt<PP_PPW + (MX ? 1 : 0)>(); else wait_vmcnt<0>();   // the bias loads are older
 #pragma unroll
-                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bvr[i][0]), "+v"(bvr[i][1]), "+v"(bvr[i][2]), "+v"(bvr[i][3]));
-            }
-            const uint32_t stg = lds0 + STG;
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bvr[i][0]), "+v"(bvr[i][1]), "+v"(bvr[i][2]), "+v"(bvr[i][3]));
+            const uint32_t stg = lds0 + ((kidx & 1) ^ 1) * STAGE;
+            uint64_t pk[NI][4][4];                            // this wave's results, packed bf16 x 4
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const int nloc = wq * WFEAT + i * 32 + 8 * gq + 4 * h;
-                    f32x4 bv;
-                    if constexpr (PIPE) bv = __builtin_bit_cast(f32x4, bvr[i][gq]);
-                    else bv = *reinterpret_cast<const f32x4 *>(bias + n0 + nloc);   // no DMA in flight: an ordinary load
+                    const f32x4 bv = __builtin_bit_cast(f32x4, bvr[i][gq]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float y0 = acc[i][j][4 * gq + 0] + bv[0], y1 = acc[i][j][4 * gq + 1] + bv[1];
@@ -423,28 +485,44 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const void *__restrict__ X
                             gelu2(y0, y1);
                             gelu2(y2, y3);
                         }
-                        const uint64_t o = (uint64_t)pack_bf16x2(y0, y1) | ((uint64_t)pack_bf16x2(y2, y3) << 32);
-                        const int row = grp * 128 + j * 32 + r;
-                        const uint32_t ad = stg + row * (BN * 2) + (((nloc >> 3) ^ (row & 15)) << 4) + ((nloc & 4) << 1);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(o) : "memory");
+                        pk[i][gq][j] = (uint64_t)pack_bf16x2(y0, y1) | ((uint64_t)pack_bf16x2(y2, y3) << 32);
                     }
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             char *obase = reinterpret_cast<char *>(out + (int64_t)m0 * N + n0);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                if (grp == pass) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int nloc = wq * WFEAT + i * 32 + 8 * gq + 4 * h;
+                                const int row = j * 32 + r;                      // row inside this pass's image
+                                const uint32_t ad = stg + row * (BN * 2) + (((nloc >> 3) ^ (row & 15)) << 4) + ((nloc & 4) << 1);
+                                asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(pk[i][gq][j]) : "memory");
+                            }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
 #pragma unroll 2
-            for (int it = 0; it < PP_BM * (BN / 8) / 512; ++it) {
-                const int sl = it * 512 + threadIdx.x;
-                const int row = sl / (BN / 8), cp = sl % (BN / 8);   // rows past M land in the padded tail of the buffer
-                u32x4 v = lds_read_b128(stg + sl * 16);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
-                *reinterpret_cast<u32x4 *>(obase + (int64_t)row * N * 2 + ((cp ^ (row & 15)) << 4)) = v;
-            }
-            if constexpr (!PIPE) {
-                __builtin_amdgcn_s_barrier();                 // the image is read: the slots may be refilled
-                if (tn < total) { set_sources(m0n, n0n); issue(kidx & 1); }
+                for (int it = 0; it < ROWS * (BN / 8) / 512; ++it) {
+                    const int sl = it * 512 + threadIdx.x;
+                    const int row = sl / (BN / 8), cp = sl % (BN / 8);   // rows past M land in the padded tail of the buffer
+                    u32x4 v = lds_read_b128_o<0>(stg + sl * 16);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
+                    *reinterpret_cast<u32x4 *>(obase + (int64_t)(pass * ROWS + row) * N * 2 + ((cp ^ (row & 15)) << 4)) = v;
+                }
+                if (pass + 1 < NPASS) __builtin_amdgcn_s_barrier();   // the image is read: the other group may overwrite it
             }
         }
+#ifdef TSIM_PP_STAMPS
+        {
+            const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+            PP_ACC(0, 1); PP_ACC(1, ts1 - ts0); PP_ACC(2, ts2 - ts1); PP_ACC(3, ts3 - ts2); PP_ACC(4, msum); PP_ACC(5, lsum); PP_ACC(6, b1sum + b2sum); PP_ACC(7, dsum);
+        }
+#endif
         if (tn >= total) break;
         t = tn;
         m0 = m0n;
@@ -535,11 +613,32 @@ __global__ __launch_bounds__(256) void quant_mx_kernel(const bf16_t *__restrict_
     }
 }
 
+// W [N, kbytes] row-major -> [N / BN][kbytes / 128][BN * 128 bytes in the kernel's LDS image order] (16 bytes per thread)
+__global__ __launch_bounds__(256) void pack_w_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ Wp, int N, int kbytes,
+                                                     int BN) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= (int64_t)N * kbytes / 16) return;
+    const int per = BN * 8, nk = kbytes / 128;
+    const int blk = (int)(u / per), sl = (int)(u % per);
+    const int nt = blk / nk, kt = blk % nk;
+    const int sr = sl >> 4, ch = (sl & 15) ^ (sr & 15);
+    const int row = sr * 2 + (ch >> 3), c = ch & 7;
+    Wp[u] = W[((int64_t)(nt * BN + row) * kbytes + kt * 128 + c * 16) / 16];
+}
+
+int pack_w(const void *W, void *Wp, int N, int kbytes, int BN, hipStream_t st) {
+    if (N % BN != 0 || kbytes % 128 != 0) return fail(TSIM_EINVAL, "pack_w: N=%d kbytes=%d BN=%d", N, kbytes, BN);
+    const int64_t units = (int64_t)N * kbytes / 16;
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const uint4 *>(W), static_cast<uint4 *>(Wp), N, kbytes, BN);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
 template <int EPI, int KSEC, bool MX, int BN = 256>
 static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint8_t *ws, const float *bias, void *out,
-                     uint8_t *out_s, int M, int N, int K, hipStream_t st) {
-    constexpr bool pipe_stage = EPI != PP_EPI_F32 && BN == 128;   // bf16 epilogue image beside the two slots
-    constexpr int lds = 2 * (PP_XB + BN * 128 + (MX ? PP_SCALES : 0)) + (pipe_stage ? PP_BM * BN * 2 : 0);
+                     uint8_t *out_s, int M, int N, int K, int wpk, hipStream_t st) {
+    constexpr int lds = 2 * (PP_XB + BN * 128 + (MX ? PP_SCALES : 0));   // the epilogue stages through the idle slot
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_pp_kernel<EPI, KSEC, MX, BN>;
     static bool attr_done = false;
@@ -553,7 +652,7 @@ static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint
     static int persist = -1;
     if (persist < 0) { const char *e = getenv("TSIM_PP_PERSIST"); persist = e ? atoi(e) : 1; }
     const int grid = persist && total > 256 ? 256 : total;     // one persistent workgroup per CU (a multiple of 8)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, out_s, M, N, K, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, xs, ws, bias, out, out_s, M, N, K, mtiles, ntiles, wpk);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -567,7 +666,9 @@ static int pp_ksec() {
     return ksec;
 }
 
-int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *out, int M, int N, int K,
+int gemm_pp_tile_width(int N) { return N % 256 != 0 ? 128 : 256; }
+
+int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, int w_packed, const float *bias, void *out, int M, int N, int K,
             hipStream_t st) {
     if (!gemm_pp_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp: N=%d K=%d not tileable by 128x64", N, K);
     if (M <= 0) return TSIM_OK;
@@ -576,15 +677,15 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
     // measured slower on the N = 768 projections even though it fills the last round of workgroups better)
     static int bn_env = -1;
     if (bn_env < 0) { const char *e = getenv("TSIM_PP_BN"); bn_env = e ? atoi(e) : 0; }
-    int bn = N % 256 != 0 ? 128 : 256;
-    if (N % 256 == 0 && bn_env == 128) bn = 128;
+    int bn = gemm_pp_tile_width(N);
+    if (N % 256 == 0 && bn_env == 128 && !w_packed) bn = 128;   // (a packed W fixes the tile width it was packed for)
 #define PP_GO(E)                                                                                              \
     do {                                                                                                      \
         if (bn == 128)                                                                                        \
-            return ksec == 1 ? launch_pp<E, 1, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st) \
-                             : launch_pp<E, 2, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st); \
-        return ksec == 1 ? launch_pp<E, 1, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st)     \
-                         : launch_pp<E, 2, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, st);    \
+            return ksec == 1 ? launch_pp<E, 1, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, w_packed, st) \
+                             : launch_pp<E, 2, false, 128>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, w_packed, st); \
+        return ksec == 1 ? launch_pp<E, 1, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, w_packed, st)     \
+                         : launch_pp<E, 2, false, 256>(X, W, nullptr, nullptr, bias, out, nullptr, M, N, K, w_packed, st);    \
     } while (0)
     switch (epi) {
         case PP_EPI_BIAS: PP_GO(PP_EPI_BIAS);
@@ -595,17 +696,17 @@ int gemm_pp(int epi, const bf16_t *X, const bf16_t *W, const float *bias, void *
 #undef PP_GO
 }
 
-int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, const uint8_t *Ws, const float *bias,
-               void *out, uint8_t *out_scales, int M, int N, int K, hipStream_t st) {
+int gemm_pp_mx(int epi, const uint8_t *Xq, const uint8_t *Xs, const uint8_t *Wq, int w_packed, const uint8_t *Ws,
+               const float *bias, void *out, uint8_t *out_scales, int M, int N, int K, hipStream_t st) {
     if (!gemm_pp_mx_supported(N, K)) return fail(TSIM_EUNSUPPORTED, "gemm_pp_mx: N=%d K=%d not tileable by 256x128", N, K);
     if (M <= 0) return TSIM_OK;
     switch (epi) {   // one v_mfma_scale_f32_32x32x64 step (8 MFMAs, 512 cycles) per section
-        case PP_EPI_BIAS: return launch_pp<PP_EPI_BIAS, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
-        case PP_EPI_GELU: return launch_pp<PP_EPI_GELU, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
-        case PP_EPI_F32: return launch_pp<PP_EPI_F32, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, st);
+        case PP_EPI_BIAS: return launch_pp<PP_EPI_BIAS, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, w_packed, st);
+        case PP_EPI_GELU: return launch_pp<PP_EPI_GELU, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, w_packed, st);
+        case PP_EPI_F32: return launch_pp<PP_EPI_F32, 1, true>(Xq, Wq, Xs, Ws, bias, out, nullptr, M, N, K, w_packed, st);
         case PP_EPI_GELU_MX:
             if (!out_scales) return fail(TSIM_EINVAL, "gemm_pp_mx: the MXFP8 epilogue needs a scale output");
-            return launch_pp<PP_EPI_GELU_MX, 1, true>(Xq, Wq, Xs, Ws, bias, out, out_scales, M, N, K, st);
+            return launch_pp<PP_EPI_GELU_MX, 1, true>(Xq, Wq, Xs, Ws, bias, out, out_scales, M, N, K, w_packed, st);
         default: return fail(TSIM_EINVAL, "gemm_pp_mx: unknown epilogue %d", epi);
     }
 }
@@ -641,4 +742,13 @@ int res_ln_rows(const float *y, const bf16_t *res, const float *gamma, const flo
     return TSIM_OK;
 }
 
+#ifdef TSIM_PP_STAMPS
+}  // namespace tsim
+extern "C" int tsim_debug_pp_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsim::g_pp_stamps), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(tsim::g_pp_stamps), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+namespace tsim {
+#endif
 }  // namespace tsim

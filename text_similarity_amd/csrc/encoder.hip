@@ -384,6 +384,18 @@ constexpr int XR_BN = 192, XR_BK = 64, XR_NSTAGE = 3;
 constexpr int XR_STG_ROW = 208;   // bytes per token row of the output staging image (192 + 16 pad: spreads rows over banks)
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+#ifdef TSIM_PP_STAMPS
+// DIAGNOSTIC build only (python -m text_similarity_amd.build --stamps; tools/pp_stamps.py --xres): cycles of wave 0 per
+// workgroup: [0] tile-steps, [1] wait (vmcnt + barrier), [2] DMA issue, [3] fragment reads + MFMAs, [4] epilogues,
+// [5] activation reloads, [6] items.
+__device__ unsigned long long g_xr_stamps[8];
+#define XR_T() __builtin_amdgcn_s_memtime()
+#define XR_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_xr_stamps[i], (unsigned long long)(v)); } while (0)
+#else
+#define XR_T() 0ull
+#define XR_ACC(i, v) do { } while (0)
+#endif
+
 template <int K, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
                                                         const float *__restrict__ bias, bf16_t *__restrict__ out,
@@ -435,12 +447,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
 
+    // The whole bias vector goes into LDS once per (persistent) workgroup: an ordinary global load inside the loop would make
+    // hipcc drain the W ring (s_waitcnt vmcnt(0)) at its first use, in every epilogue.  Read back with inline-asm ds_read.
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + XR_NSTAGE * STAGE +
+                              NW * 32 * XR_STG_ROW;
+    for (int p = wave; p * 256 < N; p += NW)
+        if (p * 256 + lane * 4 < N) glds16(bias + p * 256 + lane * 4, smem + XR_NSTAGE * STAGE + NW * 32 * XR_STG_ROW + p * 1024);
+    wait_vmcnt<0>();
+    auto bias4 = [&](int n) __attribute__((always_inline)) {   // bias[n .. n+3]
+        f32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(bias_lds + n * 4) : "memory");
+        return v;
+    };
+    unsigned long long xs_n = 0, xs_x = 0, xs_w = 0, xs_i = 0, xs_c = 0, xs_e = 0, xs_it = 0;   // (diagnostic build only)
     issue(0, 0);
     issue(1, 1);
     for (int tt = 0; tt < total; ++tt) {
         const int stage = tt % XR_NSTAGE;
         const int g = tt % KG;
         const int item = it0 + tt / KG;
+        const unsigned long long xt0 = XR_T();
         if (g == 0 && item / ntiles != cur_mb) {              // wave-uniform: new token block -> reload fragments
             cur_mb = item / ntiles;
             m0 = cur_mb * BMX + wave * 32;
@@ -450,9 +476,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retire these ordinary loads here
         }
+        const unsigned long long xt1 = XR_T();
         wait_vmcnt<PPW>();
         __builtin_amdgcn_s_barrier();
+        const unsigned long long xt2 = XR_T();
         issue(tt + 2, (stage + 2) % XR_NSTAGE);
+        const unsigned long long xt3 = XR_T();
         const char *ws = smem + stage * STAGE;
         // the k-group index selects which resident fragments to use: unrolled switch keeps bx[] in registers
 #pragma unroll
@@ -470,6 +499,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                 }
             }
         }
+#ifdef TSIM_PP_STAMPS
+#pragma unroll
+        for (int i = 0; i < NSUB; ++i) asm volatile("" : "+v"(acc[i]));
+#endif
+        const unsigned long long xt4 = XR_T();
+        xs_n += 1; xs_x += xt1 - xt0; xs_w += xt2 - xt1; xs_i += xt3 - xt2; xs_c += xt4 - xt3;
         if (g == KG - 1) {
             if constexpr (EPI == EPI_GELU) {
                 // VALU-bound epilogue: direct 16-byte stores (the LDS-staged form below costs four more barriers
@@ -483,9 +518,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int n = n0 + i * 32 + 8 * gq + 4 * h;
-                        const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
-                        float y0 = acc[i][4 * gq] + bv.x, y1 = acc[i][4 * gq + 1] + bv.y;
-                        float y2 = acc[i][4 * gq + 2] + bv.z, y3 = acc[i][4 * gq + 3] + bv.w;
+                        const f32x4 bv = bias4(n);
+                        float y0 = acc[i][4 * gq] + bv[0], y1 = acc[i][4 * gq + 1] + bv[1];
+                        float y2 = acc[i][4 * gq + 2] + bv[2], y3 = acc[i][4 * gq + 3] + bv[3];
                         if constexpr (EPI == EPI_GELU) {
                             gelu2(y0, y1); gelu2(y2, y3);
                         }
@@ -528,9 +563,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
                             const int n = n0 + i * 32 + 8 * gq + 4 * h;
-                            const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
-                            float y0 = acc[i][4 * gq] + bv.x, y1 = acc[i][4 * gq + 1] + bv.y;
-                            float y2 = acc[i][4 * gq + 2] + bv.z, y3 = acc[i][4 * gq + 3] + bv.w;
+                            const f32x4 bv = bias4(n);
+                            float y0 = acc[i][4 * gq] + bv[0], y1 = acc[i][4 * gq + 1] + bv[1];
+                            float y2 = acc[i][4 * gq + 2] + bv[2], y3 = acc[i][4 * gq + 3] + bv[3];
                             if constexpr (EPI == EPI_GELU) {
                                 gelu2(y0, y1); gelu2(y2, y3);
                             }
@@ -566,9 +601,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                     __builtin_amdgcn_s_barrier();   // image may be overwritten
                 }
             }
+            xs_e += XR_T() - xt4; xs_it += 1;
         }
     }
     wait_vmcnt<0>();
+    XR_ACC(0, xs_n); XR_ACC(5, xs_x); XR_ACC(1, xs_w); XR_ACC(2, xs_i); XR_ACC(3, xs_c); XR_ACC(4, xs_e); XR_ACC(6, xs_it);
 }
 
 // =====================================================================================================
@@ -903,7 +940,8 @@ static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, cons
 
 template <int EPI, int NW>
 static int gemm_xres_nw(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
-    constexpr int lds = XR_NSTAGE * XR_BN * XR_BK * 2 + NW * 32 * XR_STG_ROW;
+    constexpr int lds = XR_NSTAGE * XR_BN * XR_BK * 2 + NW * 32 * XR_STG_ROW + 8192;   // ring | output image | bias (N <= 2048)
+    if (N > 2048) return fail(TSIM_EUNSUPPORTED, "gemm_xres: N=%d > 2048", N);
     auto kern = gemm_xres_kernel<384, EPI, NW>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1096,6 +1134,14 @@ extern "C" int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, c
                       static_cast<const uint8_t *>(wq), 0, static_cast<const uint8_t *>(ws), bias, out_f32, nullptr, M, N, K,
                       reinterpret_cast<hipStream_t>(stream));
 }
+
+#ifdef TSIM_PP_STAMPS
+extern "C" int tsim_debug_xr_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsim::g_xr_stamps), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(tsim::g_xr_stamps), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" void tsim_encoder_destroy(tsim_encoder *e) {
     if (!e) return;

@@ -21,10 +21,18 @@ for _ in range(2):
     enc.forward_packed(fd, cd, pos, cols, int(np.diff(cu).max()), pooled=True, unit=True)
 torch.cuda.synchronize()
 L.tsim_debug_pp_stamps(buf, 1)
+L.tsim_debug_xr_stamps(buf, 1)
 enc.forward_packed(fd, cd, pos, cols, int(np.diff(cu).max()), pooled=True, unit=True)
 torch.cuda.synchronize()
 L.tsim_debug_pp_stamps(buf, 0)
 tiles, top, loop, epi, mf, ls, bw, dw = [buf[i] for i in range(8)]
-print(f"{preset} {wd}: {tiles} tiles (all ping-pong launches of one forward); per tile (cycles of wave 0): "
-      f"top wait {top / tiles:.0f}, k loop {loop / tiles:.0f} (MFMA sections {mf / tiles:.0f}, load sections {ls / tiles:.0f}, barriers {bw / tiles:.0f}, "
-      f"wait for the next k-tile's DMA {dw / tiles:.0f}), epilogue {epi / tiles:.0f}")
+if tiles:
+    print(f"{preset} {wd}: {tiles} tiles (all ping-pong launches of one forward); per tile (cycles of wave 0): "
+          f"top wait {top / tiles:.0f}, k loop {loop / tiles:.0f} (MFMA sections {mf / tiles:.0f}, load sections {ls / tiles:.0f}, barriers {bw / tiles:.0f}, "
+          f"wait for the next k-tile's DMA {dw / tiles:.0f}), epilogue {epi / tiles:.0f}")
+    
+L.tsim_debug_xr_stamps(buf, 0)
+steps, wait, iss, comp, epi, xl, items = [buf[i] for i in range(7)]
+if steps:
+    print(f"resident-X kernel: {steps} tile-steps, {items} items; cycles of wave 0 per tile-step: wait {wait / steps:.0f}, DMA issue "
+          f"{iss / steps:.0f}, reads + MFMAs {comp / steps:.0f}, activation reload {xl / steps:.0f}; per item: epilogue {epi / max(items, 1):.0f}")

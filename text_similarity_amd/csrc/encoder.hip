@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(bias_lds + n * 4) : "memory");
         return v;
     };
-    unsigned long long xs_n = 0, xs_x = 0, xs_w = 0, xs_i = 0, xs_c = 0, xs_e = 0, xs_it = 0;   // (diagnostic build only)
+    [[maybe_unused]] unsigned long long xs_n = 0, xs_x = 0, xs_w = 0, xs_i = 0, xs_c = 0, xs_e = 0, xs_it = 0;   // (diagnostic build only)
     issue(0, 0);
     issue(1, 1);
     for (int tt = 0; tt < total; ++tt) {

@@ -627,6 +627,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
                                                         int heads, float scale, bf16_t *__restrict__ ctx) {
     constexpr int KS = DH / 16;            // k-steps of the QK^T product
     constexpr int OT = (DH + 31) / 32;     // 32-row blocks of O^T
+    constexpr int ROWB = DH * 2 < 64 ? 64 : DH * 2;   // bytes per key row of the V image (>= 32 dims, so block reads stay inside)
+    __shared__ __attribute__((aligned(16))) char vimg[4 * 32 * ROWB];
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int seq = blockIdx.x, head = blockIdx.y * 4 + wave, qb = blockIdx.z;
@@ -703,25 +706,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[s][j] = (__bf16)sc[8 * s + j];
-        // V^T fragments gathered in the matching k order
+        // V^T fragments in the matching k order.  V rows (keys) are row-major in memory; the MFMA wants, per lane, 8 keys of one
+        // head dimension.  Each lane loads half a V row with 16-byte loads into a wave-private [32 keys][ROWB] LDS image and
+        // ds_read_b64_tr_b16 hands every lane 4 keys of its dimension (a 16-lane group reads a 4-key x 16-dim block column-
+        // major; lane 4q+p of the group supplies the address of key q, dims 4p..4p+3): 2-byte gathers from global memory
+        // (16 load instructions per k-step pair) were the kernel's largest cost.  EXEC is full here (out-of-range keys and
+        // queries are clamped, not masked), as the instruction requires.
+        {
+            constexpr int CH = DH / 16;                      // 16-byte chunks per half row
+            const bf16_t *vsrc = qkv + tk * H3 + 2 * H + head * DH + h * (DH / 2);
+            uint4 vr[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) vr[c] = *reinterpret_cast<const uint4 *>(vsrc + 8 * c);
+            char *vrow = vimg + wave * (32 * ROWB) + r * ROWB + h * DH;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) *reinterpret_cast<uint4 *>(vrow + 16 * c) = vr[c];
+        }
+        __builtin_amdgcn_wave_barrier();                     // wave-private image: LDS ops of one wave execute in order
 #pragma unroll
         for (int ob = 0; ob < OT; ++ob) {
-            const int i = ob * 32 + r;
-            const bool iv = i < DH;
-            const bf16_t *vp = qkv + 2 * H + head * DH + (iv ? i : 0);
+            const bool iv = ob * 32 + r < DH;
+            const int grp16 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 vf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = k0 + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-                    const int tv = t0 + (key < S ? key : S - 1);
-                    const bf16_t raw = vp[tv * H3];
-                    vf[j] = __builtin_bit_cast(__bf16, (bf16_t)(iv ? raw : (bf16_t)0));
+                for (int half = 0; half < 2; ++half) {
+                    const int key = 16 * s + 8 * half + 4 * h + q4;              // row of the block this lane addresses
+                    const char *ad = vimg + wave * (32 * ROWB) + key * ROWB + (ob * 32 + grp16 * 16 + 4 * p4) * 2;
+                    const s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)ad);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        vf[4 * half + e] = __builtin_bit_cast(__bf16, (bf16_t)(iv ? (bf16_t)t[e] : (bf16_t)0));
                 }
                 o[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], o[ob], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_wave_barrier();                     // the next key block overwrites the image
     }
     if (qi < S) {
         const float inv = 1.0f / l;

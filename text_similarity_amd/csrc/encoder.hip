@@ -621,7 +621,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
 // FLOPs are ~S/(6H) of the layer's (<1 % at the benchmark's 16-token mean length): HBM/latency-bound.
 // =====================================================================================================
 template <int DH, bool REL>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 6 : 4))) void attention_kernel(const bf16_t *__restrict__ qkv,
                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ col,
                                                         const float *__restrict__ relb, int relw, int H,
                                                         int heads, float scale, bf16_t *__restrict__ ctx) {

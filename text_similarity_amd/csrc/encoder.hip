@@ -454,10 +454,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     for (int p = wave; p * 256 < N; p += NW)
         if (p * 256 + lane * 4 < N) glds16(bias + p * 256 + lane * 4, smem + XR_NSTAGE * STAGE + NW * 32 * XR_STG_ROW + p * 1024);
     wait_vmcnt<0>();
-    auto bias4 = [&](int n) __attribute__((always_inline)) {   // bias[n .. n+3]
-        f32x4 v;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(bias_lds + n * 4) : "memory");
-        return v;
+    // bias[n .. n+3] for the four 8-feature groups of sub-tile i: four reads in flight, one wait
+    auto bias16 = [&](int n, f32x4 (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bv[gq]) : "v"(bias_lds + (n + 8 * gq) * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
     };
     [[maybe_unused]] unsigned long long xs_n = 0, xs_x = 0, xs_w = 0, xs_i = 0, xs_c = 0, xs_e = 0, xs_it = 0;   // (diagnostic build only)
     issue(0, 0);
@@ -515,10 +517,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     #pragma unroll
                 for (int i = 0; i < NSUB; ++i) {
                     uint32_t pk[8];   // pk[2*gq], pk[2*gq+1]: this lane's 4 features of group gq as packed bf16
+                    f32x4 bvs[4];
+                    bias16(n0 + i * 32 + 4 * h, bvs);
     #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
-                        const int n = n0 + i * 32 + 8 * gq + 4 * h;
-                        const f32x4 bv = bias4(n);
+                        const f32x4 bv = bvs[gq];
                         float y0 = acc[i][4 * gq] + bv[0], y1 = acc[i][4 * gq + 1] + bv[1];
                         float y2 = acc[i][4 * gq + 2] + bv[2], y3 = acc[i][4 * gq + 3] + bv[3];
                         if constexpr (EPI == EPI_GELU) {
@@ -560,10 +563,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                     for (int il = 0; il < 3; ++il) {
                         const int i = half * 3 + il;
                         uint32_t pk[8];   // pk[2*gq], pk[2*gq+1]: this lane's 4 features of group gq as packed bf16
+                        f32x4 bvs[4];
+                        bias16(n0 + i * 32 + 4 * h, bvs);
     #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            const int n = n0 + i * 32 + 8 * gq + 4 * h;
-                            const f32x4 bv = bias4(n);
+                            const f32x4 bv = bvs[gq];
                             float y0 = acc[i][4 * gq] + bv[0], y1 = acc[i][4 * gq + 1] + bv[1];
                             float y2 = acc[i][4 * gq + 2] + bv[2], y3 = acc[i][4 * gq + 3] + bv[3];
                             if constexpr (EPI == EPI_GELU) {
@@ -589,14 +593,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     // 256 rows x 12 chunks of 16 B = 3072 chunks over NW*64 threads
+                    constexpr int NCP = BMX * 12 / (NW * 64);   // 16-byte chunks per thread: all reads in flight, one wait
+                    u32x4 cv[NCP];
     #pragma unroll
-                    for (int c0 = 0; c0 < BMX * 12; c0 += NW * 64) {
-                        const int idx = c0 + (int)threadIdx.x;
+                    for (int c = 0; c < NCP; ++c) {
+                        const int idx = c * NW * 64 + (int)threadIdx.x;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(cv[c]) : "v"(stg + (idx / 12) * XR_STG_ROW + (idx % 12) * 16) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    #pragma unroll
+                    for (int c = 0; c < NCP; ++c) {
+                        asm volatile("" : "+v"(cv[c]));
+                        const int idx = c * NW * 64 + (int)threadIdx.x;
                         const int row = idx / 12, ch = idx % 12;
-                        u32x4 v;
-                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(stg + row * XR_STG_ROW + ch * 16) : "memory");
                         if (mb0 + row < M)
-                            *reinterpret_cast<u32x4 *>(out + (int64_t)(mb0 + row) * N + n0 + half * 96 + ch * 8) = v;
+                            *reinterpret_cast<u32x4 *>(out + (int64_t)(mb0 + row) * N + n0 + half * 96 + ch * 8) = cv[c];
                     }
                     __builtin_amdgcn_s_barrier();   // image may be overwritten
                 }

@@ -12,3 +12,11 @@ int k1_launch_blockmax(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, co
     return launch_k1_kl<16, true>(p, D, eq, Q, ec, N, bmax, nullptr, nullptr, st);
 }
 }  // namespace tsim
+
+#ifdef TSIM_PP_STAMPS
+extern "C" int tsim_debug_k1_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsim::g_k1_stamps), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(tsim::g_k1_stamps), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

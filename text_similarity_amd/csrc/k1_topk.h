@@ -85,11 +85,24 @@ constexpr int k1_lds_bytes() {
 // writes it to part_s[query][partition]; the KL-th largest of a query's block maxima (distinct rows by construction)
 // is a valid lower bound of its final KL-th best score (thr_select_kernel), with which the main pass starts.
 // PAIR = two tiles per barrier (ring of two 2-tile stages) instead of one tile per barrier (ring of three tiles).
+#ifdef TSIM_PP_STAMPS
+// DIAGNOSTIC build only (python -m text_similarity_amd.build --stamps; tools/pp_stamps.py --search): cycles of wave 0 of every
+// workgroup of the main pass: [0] tile pairs, [1] wait for the pair's DMA, [2] barrier, [3] DMA issue, [4] fragment reads +
+// MFMAs + selection, [5] prologue (query fragments, thresholds), [6] epilogue (drain, list write-out), [7] workgroups.
+static __device__ unsigned long long g_k1_stamps[8];
+#define K1_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define K1_STAMP(v) do { } while (0)
+#endif
+
 template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
     int *__restrict__ part_i) {
+#ifdef TSIM_PP_STAMPS
+    const unsigned long long ks_tk = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = D * 2;                        // bytes per corpus row
     constexpr int STAGE_BYTES = K1_TILE_ROWS * ROWB;   // 24 KiB at D = 384
@@ -318,17 +331,31 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         if constexpr (QW > 1) filter(std::integral_constant<int, 1>{}, acc[QW - 1], t);
     };
 
+#ifdef TSIM_PP_STAMPS
+    unsigned long long ks_n = 0, ks_dma = 0, ks_bar = 0, ks_iss = 0, ks_cmp = 0;
+    const unsigned long long ks_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (PAIR) {
         // stage = two tiles; stages alternate between slots {0,1} and {2,3}.  At the barrier of pair p everyone has
         // finished pair p-1, whose slots are exactly those of pair p+1, which is then issued and has one pair-time
         // (~48 MFMAs per wave) to land.
         auto do_pair = [&](int t, int slot) __attribute__((always_inline))  {
+            K1_STAMP(s0);
             wait_vmcnt<0>();
+            K1_STAMP(s1);
             __builtin_amdgcn_s_barrier();
+            K1_STAMP(s2);
             issue_tile(t + 2, (slot + 2) & 3);
             issue_tile(t + 3, (slot + 3) & 3);
+            K1_STAMP(s3);
             compute_tile(t, slot);
             if (t + 1 < ntiles) compute_tile(t + 1, slot + 1);
+#ifdef TSIM_PP_STAMPS
+            {
+                const unsigned long long s4 = __builtin_amdgcn_s_memtime();
+                ks_n += 1; ks_dma += s1 - s0; ks_bar += s2 - s1; ks_iss += s3 - s2; ks_cmp += s4 - s3;
+            }
+#endif
         };
         int t = 0;
         for (; t + 4 <= ntiles; t += 4) {
@@ -354,6 +381,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         if (t + 1 < ntiles) do_tile(t + 1, 1);
     }
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
+#ifdef TSIM_PP_STAMPS
+    const unsigned long long ks_t1 = __builtin_amdgcn_s_memtime();
+#endif
 
     if (wave_on) {
         const int P2 = nchunks * 2;
@@ -383,6 +413,16 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         flush(std::integral_constant<int, 0>{});
         if constexpr (QW > 1) flush(std::integral_constant<int, 1>{});
     }
+#ifdef TSIM_PP_STAMPS
+    if constexpr (PAIR && !MAXONLY) {
+        if (threadIdx.x == 0) {
+            const unsigned long long ks_t2 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_k1_stamps[0], ks_n); atomicAdd(&g_k1_stamps[1], ks_dma); atomicAdd(&g_k1_stamps[2], ks_bar);
+            atomicAdd(&g_k1_stamps[3], ks_iss); atomicAdd(&g_k1_stamps[4], ks_cmp);
+            atomicAdd(&g_k1_stamps[5], ks_t0 - ks_tk); atomicAdd(&g_k1_stamps[6], ks_t2 - ks_t1); atomicAdd(&g_k1_stamps[7], 1ull);
+        }
+    }
+#endif
 }
 
 struct TopkPlan {

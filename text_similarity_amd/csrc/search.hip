@@ -436,6 +436,10 @@ extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64
     } else {
         TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
     }
+#ifdef TSIM_PP_STAMPS
+    if (getenv("TSIM_K1_DIAG_NOSEL"))   // DIAGNOSTIC: thresholds nothing can pass (results are wrong): the time without selection
+        TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, (size_t)Q * 4, st));
+#endif
     hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -94,6 +95,20 @@ static __device__ unsigned long long g_k1_stamps[8];
 #else
 #define K1_STAMP(v) do { } while (0)
 #endif
+
+template <int... I, class F>
+__device__ __forceinline__ void k1_static_for(std::integer_sequence<int, I...>, F &&f) {   // f(integral_constant<I>) for each I
+    (f(std::integral_constant<int, I>{}), ...);
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t k1_u32x4;
+template <int OFF>
+__device__ __forceinline__ void k1_lds_read(k1_u32x4 &dst, uint32_t addr) {   // ds_read_b128 at addr + immediate offset
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k1_lgkm_wait(k1_u32x4 &consumed) {   // all but the N youngest LDS operations are done
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(consumed) : "n"(N) : "memory");
+}
 
 template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
@@ -299,24 +314,48 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[u][g] = 0.f;
         if constexpr (QW == 1) {
-            // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step
-            // s, so an LDS read has PF MFMAs (PF*32 pipe cycles) to land; sched_group_barrier pins the interleave and
-            // the compiler's counted lgkmcnt waits follow from it.
-            constexpr int PF = 4;
-            bf16x8 fr[PF + 1];
+            if constexpr (KL <= 16) {
+                // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step s, so an
+                // LDS read has PF MFMAs (PF*32 pipe cycles) to land.  Reads and waits are inline asm with COUNTED waits
+                // (lgkmcnt(PF): the PF younger reads stay in flight): hipcc's own schedule waited lgkmcnt(0) every fifth MFMA,
+                // i.e. for the read it had just issued.
+                constexpr int PF = 4;
+                k1_u32x4 fr[PF + 1];
+                const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + stage * STAGE_BYTES;
+                auto rd = [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int n = decltype(nc)::value;
+                    k1_lds_read<(n >> 3) * 256>(fr[n % (PF + 1)], lbase + aoff[n & 7]);
+                };
+                auto step = [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int sidx = decltype(sc)::value;
+                    if constexpr (sidx + PF < KSTEPS) rd(std::integral_constant<int, sidx + PF>{});
+                    constexpr int younger = sidx + PF < KSTEPS ? PF : KSTEPS - 1 - sidx;
+                    k1_lgkm_wait<younger>(fr[sidx % (PF + 1)]);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[sidx % (PF + 1)]), bq[0][sidx],
+                                                                     acc[0], 0, 0, 0);
+                };
+                k1_static_for(std::make_integer_sequence<int, PF>{}, rd);
+                k1_static_for(std::make_integer_sequence<int, KSTEPS>{}, step);
+            } else {   // KL = 32: 64 list registers leave no room for the asm pipeline without spills; compiler-scheduled form
+                // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step
+                // s, so an LDS read has PF MFMAs (PF*32 pipe cycles) to land; sched_group_barrier pins the interleave and
+                // the compiler's counted lgkmcnt waits follow from it.
+                constexpr int PF = 4;
+                bf16x8 fr[PF + 1];
 #pragma unroll
-            for (int i = 0; i < PF; ++i)
-                fr[i] = *reinterpret_cast<const bf16x8 *>(abase + aoff[i & 7] + (i >> 3) * 256);
-            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+                for (int i = 0; i < PF; ++i)
+                    fr[i] = *reinterpret_cast<const bf16x8 *>(abase + aoff[i & 7] + (i >> 3) * 256);
+                __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (s + PF < KSTEPS) {
-                    const int n = s + PF;
-                    fr[n % (PF + 1)] = *reinterpret_cast<const bf16x8 *>(abase + aoff[n & 7] + (n >> 3) * 256);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int s = 0; s < KSTEPS; ++s) {
+                    if (s + PF < KSTEPS) {
+                        const int n = s + PF;
+                        fr[n % (PF + 1)] = *reinterpret_cast<const bf16x8 *>(abase + aoff[n & 7] + (n >> 3) * 256);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % (PF + 1)], bq[0][s], acc[0], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % (PF + 1)], bq[0][s], acc[0], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         } else {
 #pragma unroll

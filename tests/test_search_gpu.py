@@ -118,6 +118,28 @@ def test_many_duplicates_and_zero_rows():
     assert i[1].tolist() == list(range(10)) and (s[1] == 0).all()
 
 
+@pytest.mark.parametrize("k", [10, 19])
+def test_zero_query_and_zero_rows_with_threshold_prepass(k):
+    """N >= 262144 switches the threshold pre-pass on.  A zero query scores exactly 0 against every row, so the bound it
+    derives is 0.0 and every row ties: the k lowest indices must come back (found by tools/fuzz_search.py: the float
+    'below' +0.0 in key order is -0.0, which compares equal, and the filter then rejected everything).  A query whose
+    best scores are a mix of exact zeros (zero corpus rows) and negatives is checked as well."""
+    N, d = 300_000, 128
+    rng = np.random.default_rng(11)
+    c = rng.standard_normal((N, d)).astype(np.float32)
+    c[rng.integers(0, N, N // 10)] = 0.0
+    q = rng.standard_normal((33, d)).astype(np.float32)
+    q[0] = 0.0
+    q[1] = -np.abs(q[1])
+    c[::7] = -np.abs(c[::7]) * (c[::7] != 0)          # many rows with all-negative entries: negative cosines with q[1]
+    s, i = ops.cosine_topk(ops.l2norm_rows(torch.from_numpy(q).to(DEV)), ops.l2norm_rows(torch.from_numpy(c).to(DEV)), d, k)
+    torch.cuda.synchronize()
+    assert i[0].tolist() == list(range(k)) and (s[0] == 0).all()
+    rs, ri = search_ref.cosine_topk(search_ref.unit_rows(q[:6]), search_ref.unit_rows(c), k)
+    np.testing.assert_array_equal(i[:6].cpu().numpy(), ri)
+    np.testing.assert_array_equal(s[:6].cpu().numpy(), rs)
+
+
 def test_anisotropic_scores_near_ties():
     # rows = common direction + small noise: all cosines ~0.99, gaps ~1e-4 (random-weight encoders look like this)
     base = presets.normal("aniso/base", 384)

@@ -60,8 +60,13 @@ __device__ __forceinline__ int float_to_ordered(float f) {
 __device__ __forceinline__ float ordered_to_float(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 constexpr int K1_GTHR_INIT = (int)0x80808080;  // memset byte 0x80: below every finite score
 // bound published by another lane -> strict '>' filter value: the next float BELOW it (keeps equal scores eligible)
+// A bound of +0.0 or -0.0 (ordered keys 0 and -1: e.g. an all-zero query scores exactly 0 against everything) must admit
+// both zeros, and the float "below" +0.0 in key order is -0.0, which compares EQUAL to it: use the smallest normal
+// negative number there (a weaker filter is always safe; it also keeps the test independent of the denormal mode).
 __device__ __forceinline__ float import_threshold(int key) {
-    return key <= K1_GTHR_INIT ? -INFINITY : ordered_to_float(key - 1);
+    if (key <= K1_GTHR_INIT) return -INFINITY;
+    if (key == 0 || key == -1) return -1.17549435e-38f;
+    return ordered_to_float(key - 1);
 }
 
 template <int D, int NWAVES, int QW, bool PAIR = false>

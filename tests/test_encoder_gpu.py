@@ -102,6 +102,10 @@ def test_empty_and_degenerate_inputs():
     cu = torch.tensor([0, 0, 3, 3], dtype=torch.int32, device=DEV)
     p = enc.forward_packed(flat, cu)["pooled"]
     assert (p[0] == 0).all() and (p[2] == 0).all() and p[1].abs().sum() > 0
+    # a batch of ONLY empty sequences (no tokens at all): zero rows, no error
+    p0 = enc.forward_packed(torch.zeros(0, dtype=torch.int32, device=DEV), torch.zeros(4, dtype=torch.int32, device=DEV),
+                            pooled=True, unit=True)
+    assert p0["pooled"].shape == (3, enc.cfg.hidden) and (p0["pooled"] == 0).all() and (p0["unit"] == 0).all()
     with pytest.raises(ValueError):
         enc.forward_packed(torch.zeros(300, dtype=torch.int32, device=DEV),
                            torch.tensor([0, 300], dtype=torch.int32, device=DEV))

@@ -1185,7 +1185,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                                     const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
                                     int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit,
                                     void *last_hidden_bf16, void *stream) {
-    TSIM_REQUIRE(e && tok_ids && tok_pos && cu_seqlens, "encoder_forward: null pointer");
+    TSIM_REQUIRE(e && cu_seqlens && (T == 0 || (tok_ids && tok_pos)), "encoder_forward: null pointer");   // T = 0: only empty sequences
     TSIM_REQUIRE(T >= 0 && B >= 0 && T <= e->cfg.max_tokens && B <= e->cfg.max_seqs,
                  "encoder_forward: T=%d B=%d exceed capacity (%d tokens, %d sequences)", T, B, e->cfg.max_tokens, e->cfg.max_seqs);
     TSIM_REQUIRE(max_len <= e->cfg.max_pos, "encoder_forward: max_len=%d > max_pos=%d", max_len, e->cfg.max_pos);

@@ -89,5 +89,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
 
 if __name__ == "__main__":
     # --stamps: DIAGNOSTIC build of the ping-pong GEMM with in-kernel cycle stamps (tools/pp_stamps.py); rebuild without it after
-    build(force="--force" in sys.argv or "--stamps" in sys.argv, extra_flags=["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else ())
+    # -DNAME arguments are passed through to hipcc (A/B builds of compile-time variants; they force a rebuild)
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    build(force="--force" in sys.argv or "--stamps" in sys.argv or bool(defs),
+          extra_flags=(["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else []) + defs)
     print(LIB)

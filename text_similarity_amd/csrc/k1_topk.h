@@ -282,26 +282,36 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             for (int g = 0; g < 16; ++g)
                 if (trow + (g & 3) + 8 * (g >> 2) >= crows) acc[g] = -INFINITY;
         }
-        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+        // maxima of the four 4-register groups first (four independent chains), then their maximum: the rare candidate path
+        // below only scans the groups that hold one (a wave ballot per group, then per register of a hit group, instead of
+        // one per register)
+        float mg[4];
 #pragma unroll
-        for (int g = 3; g < 15; g += 2) m = fmaxf(fmaxf(m, acc[g]), acc[g + 1]);
-        m = fmaxf(m, acc[15]);
+        for (int gq = 0; gq < 4; ++gq)
+            mg[gq] = fmaxf(fmaxf(fmaxf(acc[4 * gq], acc[4 * gq + 1]), acc[4 * gq + 2]), acc[4 * gq + 3]);
+        const float m = fmaxf(fmaxf(fmaxf(mg[0], mg[1]), mg[2]), mg[3]);
         if constexpr (MAXONLY) {
             bmax[u] = fmaxf(bmax[u], m);
             return;
         }
         if (__any(m > thr[u])) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const bool p = acc[g] > thr[u];
-                if (__any(p)) {
-                    if (p) {
-                        const uint64_t e = (uint64_t)__float_as_uint(acc[g]) |
-                                           ((uint64_t)(uint32_t)(trow + (g & 3) + 8 * (g >> 2)) << 32);
-                        asm volatile("ds_write_b64 %0, %1" ::"v"(qaddr + cnt[u] * 512), "v"(e) : "memory");
-                        cnt[u]++;
+            for (int gq = 0; gq < 4; ++gq) {
+#ifndef TSIM_K1_FLAT_SCAN
+                if (!__any(mg[gq] > thr[u])) continue;
+#endif
+#pragma unroll
+                for (int g = 4 * gq; g < 4 * gq + 4; ++g) {
+                    const bool p = acc[g] > thr[u];
+                    if (__any(p)) {
+                        if (p) {
+                            const uint64_t e = (uint64_t)__float_as_uint(acc[g]) |
+                                               ((uint64_t)(uint32_t)(trow + (g & 3) + 8 * (g >> 2)) << 32);
+                            asm volatile("ds_write_b64 %0, %1" ::"v"(qaddr + cnt[u] * 512), "v"(e) : "memory");
+                            cnt[u]++;
+                        }
+                        if (__any(cnt[u] == K1_QCAP)) drain(uc);
                     }
-                    if (__any(cnt[u] == K1_QCAP)) drain(uc);
                 }
             }
         }

@@ -33,7 +33,10 @@ namespace tsim {
 // =====================================================================================================
 constexpr int K1_TILE_ROWS = 32;
 constexpr int K1_NSTAGE = 3;   // ring slots (tiles); the PAIR variant uses 4 slots = two 2-tile stages
-constexpr int K1_QCAP = 8;  // per-lane candidate queue depth (entries)
+#ifndef TSIM_K1_QCAP
+#define TSIM_K1_QCAP 8
+#endif
+constexpr int K1_QCAP = TSIM_K1_QCAP;  // per-lane candidate queue depth (entries)
 
 template <int KL>
 __device__ __forceinline__ void list_insert(float (&ls)[KL], int (&li)[KL], float s, int i) {
@@ -334,7 +337,10 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
                 // LDS read has PF MFMAs (PF*32 pipe cycles) to land.  Reads and waits are inline asm with COUNTED waits
                 // (lgkmcnt(PF): the PF younger reads stay in flight): hipcc's own schedule waited lgkmcnt(0) every fifth MFMA,
                 // i.e. for the read it had just issued.
-                constexpr int PF = 4;
+#ifndef TSIM_K1_PF
+#define TSIM_K1_PF 4
+#endif
+                constexpr int PF = TSIM_K1_PF;
                 k1_u32x4 fr[PF + 1];
                 const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + stage * STAGE_BYTES;
                 auto rd = [&](auto nc) __attribute__((always_inline)) {

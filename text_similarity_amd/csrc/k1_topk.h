@@ -494,7 +494,10 @@ struct TopkPlan {
 // enough chunks to fill the chip; returns false when the corpus is too small for a pre-pass to pay.
 static inline bool plan_prepass(int64_t Q, int64_t N, const TopkPlan &mainp, TopkPlan *p) {
     if (N < 262144) return false;
-    const int64_t S = mainp.nqb >= 4 ? 32768 : 65536;
+#ifndef TSIM_K1_PREPASS_ROWS
+#define TSIM_K1_PREPASS_ROWS 32768
+#endif
+    const int64_t S = mainp.nqb >= 4 ? TSIM_K1_PREPASS_ROWS : 65536;
     int nch = 512 / mainp.nqb;
     if (nch < 16) nch = 16;
     if (nch > S / 64) nch = (int)(S / 64);

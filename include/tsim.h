@@ -56,16 +56,29 @@ int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld
 /* ---------------------------------------------------------------------------------------------
  * A6/A7/A9  the per-query loop `expand_as -> F.cosine_similarity -> torch.topk`
  *           /root/reference/src/pipeline/search_pipeline.py:73-78, fused.
- * eq [Q, ld] and ec [N, ld] are L2-normalised bf16 rows (tsim_l2norm_rows).  For every query the k
- * corpus rows with the largest inner product are returned, ordered by (score descending, index
- * ascending) — the tie rule torch.topk leaves undefined.  The N x Q score matrix is never written:
- * MFMA scores live in registers, survivors go through per-lane queues in LDS.  Candidates are then
- * re-scored in a fixed order (float64 accumulation over j = 0..d-1, one rounding to float32) so scores
- * and indices are reproducible bit for bit (oracle/search_ref.py canonical_scores).
- * out_scores [Q, k] float32, out_idx [Q, k] int64 = local row index + idx_offset (-1 / -inf when the
- * corpus has fewer than k rows).  k <= 28.  workspace: tsim_cosine_topk_workspace_bytes(Q, N, k). */
+ * eq_unit [Q, ld] and ec_unit [N, ld] are L2-normalised bf16 rows (tsim_l2norm_rows).  MFMA inner products of those rows
+ * (scores live in registers, survivors go through per-lane queues in LDS; the N x Q matrix is never written) SELECT
+ * candidates; every score that is returned, and the final order, comes from an exact re-score:
+ *   - eq_f32 / ec_f32 given (float32 embeddings, row strides ldq_f32 / ldc_f32 elements): the reference's value
+ *     x.y / (max(|x|, 1e-8) * max(|y|, 1e-8)) of the float32 rows, evaluated in float64 in a fixed order and rounded once
+ *     to float32 (oracle/search_ref.exact_cosine) — torch's own float32 evaluation differs from it by rounding only;
+ *   - eq_f32 == ec_f32 == NULL: the inner product of the unit rows as stored (oracle/search_ref.canonical_scores).
+ * Results are ordered by (score descending, index ascending) — the tie rule torch.topk leaves undefined.
+ * Exactness guard: a query whose k-th exact score is not clear of the MFMA scores of the rows that were NOT re-scored
+ * (by c1 x the largest |MFMA - exact| difference seen for that query, c1 = 4, env TSIM_GUARD_C1) is searched again: every
+ * row above a fixed threshold is collected and re-scored, and if that overflows or still fails the test, the whole shard
+ * is scored exactly for that query.  out_status [Q] int32 (may be NULL) reports which pass produced each row:
+ * 0 first pass, 1 widened, 2 brute force.
+ * out_scores [Q, k] float32, out_idx [Q, k] int64 = shard row index + idx_offset (-1 / -inf when the shard has fewer
+ * than k rows).  1 <= k <= 64 (k > 28 skips the list kernel: block maxima -> collect -> re-score).
+ * workspace: tsim_cosine_topk_workspace_bytes(Q, N, k).
+ * tsim_cosine_topk(...) == tsim_cosine_topk_ex with NULL float32 matrices and NULL status. */
 size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k);
-int tsim_cosine_topk(const void *eq_bf16, int64_t Q, const void *ec_bf16, int64_t N, int d, int ld,
+int tsim_cosine_topk_ex(const void *eq_unit, const float *eq_f32, int64_t ldq_f32, int64_t Q,
+                        const void *ec_unit, const float *ec_f32, int64_t ldc_f32, int64_t N,
+                        int d, int ld, int k, float *out_scores, int64_t *out_idx, int32_t *out_status,
+                        int64_t idx_offset, void *workspace, size_t workspace_bytes, void *stream);
+int tsim_cosine_topk(const void *eq_unit, int64_t Q, const void *ec_unit, int64_t N, int d, int ld,
                      int k, float *out_scores, int64_t *out_idx, int64_t idx_offset,
                      void *workspace, size_t workspace_bytes, void *stream);
 

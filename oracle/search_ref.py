@@ -14,10 +14,11 @@ arithmetic; its published semantics are restated here in numpy.  Pinned against 
 the build container by the reference's own ``cos_sim`` and by torch ``cosine_similarity``/``topk``
 (tools/make_golden.py -> tests/golden/search_*.npz); see tests/test_oracle_golden.py.
 
-Canonical score.  The GPU path scores bf16 rows with MFMA (fp32 accumulate, hardware summation order) to
-*select candidates* and then re-scores the few survivors in a fixed order so results are reproducible bit
-for bit: products of two bf16 values are exact in float64, they are accumulated in float64 in index order
-j = 0..d-1 and the sum is rounded once to float32.  ``canonical_scores`` is that definition.
+Exact scores.  The GPU path scores bf16 unit rows with MFMA (fp32 accumulate, hardware summation order) only to
+*select candidates*; every returned score and the final order come from an exact re-score in float64 in one fixed
+("lane") order, rounded once to float32, so results are reproducible bit for bit:
+``exact_cosine`` — the reference's F.cosine_similarity of the float32 embeddings (what ``cosine_topk_f32`` ranks), and
+``canonical_scores`` — the inner product of the stored unit rows, for callers that hold unit rows only.
 """
 from __future__ import annotations
 
@@ -100,25 +101,88 @@ def cos_sim(a: np.ndarray, b: np.ndarray) -> np.ndarray:
         return (an.astype(np.float64) @ bn.astype(np.float64).T).astype(np.float32)
 
 
-def canonical_scores(eq: np.ndarray, ec: np.ndarray) -> np.ndarray:
-    """[Q,N] float32: sequential float64 accumulation over j = 0..d-1 of eq[:,j]*ec[:,j], one final
-    rounding to float32.  Inputs are the (bf16-exact) normalised rows."""
-    eq = np.asarray(eq, dtype=np.float64)
-    ec = np.asarray(ec, dtype=np.float64)
-    acc = np.zeros((eq.shape[0], ec.shape[0]), dtype=np.float64)
-    for j in range(eq.shape[1]):
-        acc += eq[:, j:j + 1] * ec[None, :, j]
-    return acc.astype(np.float32)
+_LANES = np.arange(64)
+
+
+def _lane_sum(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """Canonical float64 inner product along the last axis of two broadcastable float arrays, in the order the GPU's
+    wave-cooperative re-score uses (text_similarity_amd/csrc/search.hip wave_dot_f64): lane l accumulates the products of
+    elements j = l, l + 64, l + 128, ... in that order, then an xor butterfly 32, 16, .., 1 adds the 64 lane partials.
+    Products of two float32 (or narrower) values are exact in float64, so fma == multiply + add and numpy reproduces
+    the kernel bit for bit."""
+    d = x.shape[-1]
+    m = -(-d // 64)
+    pad = m * 64 - d
+
+    def lanes(a):
+        a = np.asarray(a, dtype=np.float64)
+        if pad:
+            a = np.concatenate([a, np.zeros(a.shape[:-1] + (pad,))], axis=-1)
+        return a.reshape(a.shape[:-1] + (m, 64))
+
+    xl, yl = lanes(x), lanes(y)
+    part = xl[..., 0, :] * yl[..., 0, :]
+    for i in range(1, m):
+        part = part + xl[..., i, :] * yl[..., i, :]
+    for o in (32, 16, 8, 4, 2, 1):
+        part = part + part[..., _LANES ^ o]
+    return part[..., 0]
+
+
+def exact_cosine(q: np.ndarray, c: np.ndarray, eps: float = 1e-8, qblock: int = 16, nblock: int = 8192) -> np.ndarray:
+    """[Q,N] float32: the reference's score, F.cosine_similarity(q_row.expand_as(c), c, dim=-1)
+    (/root/reference/src/pipeline/search_pipeline.py:76-77) = x.y / (max(||x||, eps) * max(||y||, eps)) on the float32
+    rows, evaluated in float64 (canonical order: _lane_sum) and rounded ONCE to float32.  torch evaluates the same formula
+    in float32, so its values differ from this one by float32 rounding (<= 4e-7 on the goldens); this is the definition
+    the GPU's fp32 re-score (tsim_cosine_topk_ex) reproduces bit for bit."""
+    q = np.asarray(q, dtype=np.float32)
+    c = np.asarray(c, dtype=np.float32)
+    e = np.float64(np.float32(eps))
+    nq = np.maximum(np.sqrt(_lane_sum(q, q)), e)
+    nc = np.maximum(np.sqrt(_lane_sum(c, c)), e)
+    out = np.empty((q.shape[0], c.shape[0]), dtype=np.float32)
+    for a in range(0, q.shape[0], qblock):
+        for b in range(0, c.shape[0], nblock):
+            dot = _lane_sum(q[a:a + qblock, None, :], c[None, b:b + nblock, :])
+            out[a:a + qblock, b:b + nblock] = (dot / (nq[a:a + qblock, None] * nc[None, b:b + nblock])).astype(np.float32)
+    return out
+
+
+def exact_cosine_pairs(q: np.ndarray, c: np.ndarray, qi: np.ndarray, ci: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """exact_cosine of selected (query, corpus) index pairs."""
+    x = np.asarray(q, dtype=np.float32)[qi]
+    y = np.asarray(c, dtype=np.float32)[ci]
+    e = np.float64(np.float32(eps))
+    return (_lane_sum(x, y) / (np.maximum(np.sqrt(_lane_sum(x, x)), e) * np.maximum(np.sqrt(_lane_sum(y, y)), e))
+            ).astype(np.float32)
+
+
+def cosine_topk_f32(q: np.ndarray, c: np.ndarray, k: int, idx_offset: int = 0, block: int = 16):
+    """The reference's search on float32 embeddings (search_pipeline.py:73-78: expand_as + F.cosine_similarity +
+    torch.topk per query) with the tie rule fixed as (score desc, index asc): exact top-k of exact_cosine."""
+    vals, idxs = [], []
+    for s in range(0, q.shape[0], block):
+        v, i = topk_rows(exact_cosine(q[s:s + block], c), k)
+        vals.append(v)
+        idxs.append(i + idx_offset)
+    return np.concatenate(vals), np.concatenate(idxs)
+
+
+def canonical_scores(eq: np.ndarray, ec: np.ndarray, qblock: int = 16, nblock: int = 8192) -> np.ndarray:
+    """[Q,N] float32: inner product of the stored unit rows, float64 accumulation in the canonical lane order
+    (_lane_sum), one final rounding to float32.  Inputs are the (bf16-exact) normalised rows."""
+    eq = np.asarray(eq, dtype=np.float32)
+    ec = np.asarray(ec, dtype=np.float32)
+    out = np.empty((eq.shape[0], ec.shape[0]), dtype=np.float32)
+    for a in range(0, eq.shape[0], qblock):
+        for b in range(0, ec.shape[0], nblock):
+            out[a:a + qblock, b:b + nblock] = _lane_sum(eq[a:a + qblock, None, :], ec[None, b:b + nblock, :]).astype(np.float32)
+    return out
 
 
 def canonical_scores_pairs(eq: np.ndarray, ec: np.ndarray, qi: np.ndarray, ci: np.ndarray) -> np.ndarray:
     """canonical score of selected (query, corpus) index pairs."""
-    a = np.asarray(eq, dtype=np.float64)[qi]
-    b = np.asarray(ec, dtype=np.float64)[ci]
-    acc = np.zeros(a.shape[0], dtype=np.float64)
-    for j in range(a.shape[1]):
-        acc += a[:, j] * b[:, j]
-    return acc.astype(np.float32)
+    return _lane_sum(np.asarray(eq, dtype=np.float32)[qi], np.asarray(ec, dtype=np.float32)[ci]).astype(np.float32)
 
 
 def topk_rows(scores: np.ndarray, k: int):
@@ -162,14 +226,11 @@ def merge_topk(values, indices, k: int):
 
 
 def mining_search(query_emb: np.ndarray, corpus_emb: np.ndarray, k: int, chunk: int):
-    """search_pipeline.py:60-89 as intended: for each corpus chunk, each query row is
-    scored against every chunk row with cosine_similarity and the k best are kept; chunks are merged.
-    Inputs float32 un-normalised embeddings; scoring on bf16-rounded unit rows like the GPU path."""
-    qn = unit_rows(query_emb)
+    """search_pipeline.py:60-89 as intended: for each corpus chunk, each query row is scored against
+    every chunk row with F.cosine_similarity on the float32 embeddings and the k best are kept; chunks are merged."""
     vs, ix = [], []
     for s in range(0, corpus_emb.shape[0], chunk):
-        cn = unit_rows(corpus_emb[s:s + chunk])
-        v, i = cosine_topk(qn, cn, k, idx_offset=s)
+        v, i = cosine_topk_f32(query_emb, corpus_emb[s:s + chunk], k, idx_offset=s)
         vs.append(v)
         ix.append(i)
     return merge_topk(vs, ix, k)

@@ -35,7 +35,8 @@ def test_pure_host_entry_points(lib):
     assert lib.tsim_version() >= 100
     assert [lib.tsim_pad_dim(d) for d in (1, 64, 128, 129, 384, 385, 768, 769)] == [128, 128, 128, 256, 384, 512, 768, 0]
     assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 10) > 0
-    assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 29) == 0
+    assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 64) > 0       # k > 28: no list kernel, still served
+    assert lib.tsim_cosine_topk_workspace_bytes(256, 1_000_000, 65) == 0      # k <= 64
     with pytest.raises(ValueError):
         ops.pad_dim(1000)
 
@@ -45,7 +46,11 @@ def test_argument_validation_returns_error_codes(lib):
     p = ctypes.addressof(buf)
     # k out of range, empty corpus, wrong row stride, null pointers: all rejected before any launch
     assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 0, p, p, 0, p, 4096, None) == 1
-    assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 40, p, p, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 65, p, p, 0, p, 4096, None) == 1
+    # float32 matrices: both or neither; strides at least d
+    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, None, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk_ex(p, p, 100, 4, p, p, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, p, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 3   # workspace
     assert lib.tsim_cosine_topk(p, 4, p, 0, 384, 384, 10, p, p, 0, p, 4096, None) == 1
     assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 400, 10, p, p, 0, p, 4096, None) == 1
     assert b"tsim_pad_dim" in lib.tsim_last_error()

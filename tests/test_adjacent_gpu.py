@@ -86,7 +86,7 @@ def test_ranking_pipeline_retrieve_then_rerank():
     queries = ["w3", "w250", "w77"]
     pipe = RankingPipeline(_FakeCross(), 128, SimpleNamespace(device=DEV), _FakeModel(table))
     out = pipe(queries, corpus, top_k=6)
-    sc, ix = search_ref.cosine_topk(search_ref.unit_rows(table[[3, 250, 77]]), search_ref.unit_rows(table[100:400]), 6)
+    sc, ix = search_ref.cosine_topk_f32(table[[3, 250, 77]], table[100:400], 6)      # the reference's float32 cosine
     for qi, res in enumerate(out):
         assert sorted(r["corpus_id"] for r in res["results"]) == sorted(ix[qi].tolist())
         cs = [r["cross-score"] for r in res["results"]]

@@ -14,7 +14,7 @@ DEV = "cuda:0"
 
 
 def _oracle(q, live_rows, live_labels, k):
-    s, i = search_ref.cosine_topk(search_ref.unit_rows(q), search_ref.unit_rows(live_rows), k)
+    s, i = search_ref.cosine_topk_f32(q, live_rows, k)      # the reference's cosine of the float32 rows
     return live_labels[i], s
 
 
@@ -58,6 +58,11 @@ def test_add_query_delete_persist(tmp_path):
     idx2.load_index(str(tmp_path))
     lab3, sc3 = idx2.search(q, 10)
     assert torch.equal(lab3, lab2) and torch.equal(sc3, sc2)
+    # k = 50 (the reference's bound is ef = 50, search_pipeline.py:131)
+    lab50, sc50 = idx2.search(q[:4], 50)
+    rl50, rs50 = _oracle(q[:4], x[keep], labels[keep], 50)
+    np.testing.assert_array_equal(lab50.cpu().numpy(), rl50)
+    np.testing.assert_array_equal(sc50.cpu().numpy(), rs50)
     # fewer live rows than k
     small = GpuFlatIndex(dim=d, device=DEV)
     small.add_items(x[:4])

@@ -15,13 +15,20 @@ from text_similarity_amd import presets
 from text_similarity_amd.distributed.sharded_search import ShardedCorpusSearch, shard_bounds
 
 
-def _oracle_local(q_unit, c_unit, d, k, offset):
-    v, i = search_ref.cosine_topk(q_unit[:, :d].float().numpy(), c_unit[:, :d].float().numpy(), k, idx_offset=offset)
+def _pad(v, i, k):
     if v.shape[1] < k:
         pad = k - v.shape[1]
         v = np.concatenate([v, np.full((v.shape[0], pad), -np.inf, np.float32)], 1)
         i = np.concatenate([i, np.full((i.shape[0], pad), -1, np.int64)], 1)
     return torch.from_numpy(v), torch.from_numpy(i)
+
+
+def _oracle_local(q, c_unit, c_f32, d, k, offset):
+    if c_f32 is None:      # unit rows only: inner products of the stored rows
+        v, i = search_ref.cosine_topk(q[:, :d].float().numpy(), c_unit[:, :d].float().numpy(), k, idx_offset=offset)
+    else:                  # float32 embeddings: the reference's cosine
+        v, i = search_ref.cosine_topk_f32(q.numpy(), c_f32.numpy(), k, idx_offset=offset)
+    return _pad(v, i, k)
 
 
 def _oracle_merge(scores, idx, k):
@@ -33,41 +40,66 @@ def _oracle_merge(scores, idx, k):
     return torch.from_numpy(v), torch.from_numpy(i)
 
 
-def _worker(rank, world, port, n_total, k, out_dir):
+def _data(n_total, world):
+    corpus = presets.synthetic_embeddings(n_total, 384, "shard/c")
+    corpus[n_total - 1] = corpus[3]          # a duplicate living on the LAST shard: tie must resolve to row 3
+    queries = presets.synthetic_embeddings(8 * world, 384, "shard/q")
+    queries[0] = corpus[3]
+    return corpus, queries
+
+
+def _worker(rank, world, port, n_total, k, mode, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        d, ld = 384, 384
-        corpus = presets.synthetic_embeddings(n_total, d, "shard/c")
-        corpus[n_total - 1] = corpus[3]          # a duplicate living on the LAST shard: tie must resolve to row 3
-        queries = presets.synthetic_embeddings(8 * world, d, "shard/q")
-        queries[0] = corpus[3]
+        d = 384
+        corpus, queries = _data(n_total, world)
         lo, hi = shard_bounds(n_total, world, rank)
-        c_local = torch.from_numpy(corpus[lo:hi]).to(torch.bfloat16)
-        q_local = torch.from_numpy(queries[rank * 8:(rank + 1) * 8]).to(torch.bfloat16)
-        eng = ShardedCorpusSearch(c_local, d, lo, local_search=_oracle_local, merge=_oracle_merge)
-        s, i = eng.search(q_local, k)
-        np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy())
+        c_unit = torch.from_numpy(search_ref.unit_rows(corpus[lo:hi])).to(torch.bfloat16)
+        if mode == "unit":
+            q_local = torch.from_numpy(search_ref.unit_rows(queries[rank * 8:(rank + 1) * 8])).to(torch.bfloat16)
+            eng = ShardedCorpusSearch(c_unit, d, lo, local_search=_oracle_local, merge=_oracle_merge)
+        else:
+            # un-normalised float32 embeddings (scaled rows: the cosine must not care)
+            scale = (1.0 + np.arange(n_total, dtype=np.float32) % 7)[:, None]
+            q_local = torch.from_numpy(queries[rank * 8:(rank + 1) * 8] * 3.0)
+            eng = ShardedCorpusSearch(c_unit, d, lo, local_search=_oracle_local, merge=_oracle_merge,
+                                      corpus_f32_local=torch.from_numpy((corpus * scale)[lo:hi]))
+        if mode == "f32-stream":   # the pipelined form over two batches gives the same lists
+            outs = list(eng.search_stream(iter([q_local, q_local.flip(0)]), k))
+            s, i = outs[0]
+            s2, i2 = outs[1]
+            np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy(), s2=s2.numpy(), i2=i2.numpy())
+        else:
+            s, i = eng.search(q_local, k)
+            np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,k", [(1001, 10), (15, 10)])
-def test_two_rank_sharded_search_equals_unsharded(tmp_path, n_total, k):
+@pytest.mark.parametrize("n_total,k,mode", [(1001, 10, "unit"), (15, 10, "unit"), (1001, 10, "f32"), (15, 10, "f32"),
+                                            (500, 5, "f32-stream")])
+def test_two_rank_sharded_search_equals_unsharded(tmp_path, n_total, k, mode):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     world = 2
-    mp.spawn(_worker, args=(world, port, n_total, k, str(tmp_path)), nprocs=world, join=True)
-    corpus = presets.synthetic_embeddings(n_total, 384, "shard/c")
-    corpus[n_total - 1] = corpus[3]
-    queries = presets.synthetic_embeddings(8 * world, 384, "shard/q")
-    queries[0] = corpus[3]
-    ref_s, ref_i = search_ref.cosine_topk(queries, corpus, k)
+    mp.spawn(_worker, args=(world, port, n_total, k, mode, str(tmp_path)), nprocs=world, join=True)
+    corpus, queries = _data(n_total, world)
+    if mode == "unit":
+        ref_s, ref_i = search_ref.cosine_topk(search_ref.unit_rows(queries), search_ref.unit_rows(corpus), k)
+    else:
+        scale = (1.0 + np.arange(n_total, dtype=np.float32) % 7)[:, None]
+        ref_s, ref_i = search_ref.cosine_topk_f32(queries * 3.0, corpus * scale, k)
+    ref_s, ref_i = (t.numpy() for t in _pad(ref_s, ref_i, k))
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npz")
         np.testing.assert_array_equal(got["i"], ref_i)
         np.testing.assert_array_equal(got["s"], ref_s)
+        if mode == "f32-stream":   # second batch: every rank's slice reversed
+            perm = np.concatenate([np.arange(8 * w, 8 * w + 8)[::-1] for w in range(world)])
+            np.testing.assert_array_equal(got["i2"], ref_i[perm])
+            np.testing.assert_array_equal(got["s2"], ref_s[perm])
     assert ref_i[0, 0] == 3 and ref_i[0, 1] == n_total - 1
 
 

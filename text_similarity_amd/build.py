@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtsim.so")
-SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_kl32.hip", "gemm_pp.hip", "encoder.hip"]
+SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip"]
 HOT_KERNELS = ("cos_topk_partial", "gemm_bf16", "gemm_xres", "gemm_pp", "attention_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]

@@ -118,11 +118,23 @@ __device__ __forceinline__ void k1_lgkm_wait(k1_u32x4 &consumed) {   // all but 
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(consumed) : "n"(N) : "memory");
 }
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR>
+// COLLECT = the widening pass behind K2's exactness guard (search.hip): queries are the FLAGGED ones only (slot s of the
+// launch = query coll.qmap[s], *coll.qcount slots in all, known on the device only), every lane filters with the FIXED
+// threshold gthr[slot] (no lists, nothing published) and appends every (score, shard row) above it to the slot's buffer
+// coll.buf[slot * cap ..] through an atomic counter coll.cnt[slot]; a counter beyond cap means the slot overflowed.
+struct K1Collect {
+    const int *qcount;           // device: number of slots (<= Q)
+    const int *qmap;             // device: slot -> query row
+    unsigned long long *buf;     // [Q][cap] entries: score bits | (uint64)(shard row) << 32
+    int *cnt;                    // [Q] entries appended per slot (may exceed cap)
+    int cap;
+};
+
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
-    int *__restrict__ part_i) {
+    int *__restrict__ part_i, K1Collect coll) {
 #ifdef TSIM_PP_STAMPS
     const unsigned long long ks_tk = __builtin_amdgcn_s_memtime();
 #endif
@@ -155,6 +167,11 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         qb = jj * per + xcd / nchunks;
     }
     if (chunk >= nchunks || qb >= nqb) return;
+    if constexpr (COLLECT) {   // the slot count lives on the device: query blocks past it leave (workgroup-uniform)
+        const int qe = *coll.qcount;
+        Q = qe < Q ? qe : Q;
+        if (qb * (NWAVES * 32 * QW) >= Q) return;
+    }
 
     const int64_t row0 = (int64_t)chunk * rows_per_chunk;
     const int crows = (int)(((N - row0) < (int64_t)rows_per_chunk) ? (N - row0) : (int64_t)rows_per_chunk);
@@ -169,7 +186,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
     for (int u = 0; u < QW; ++u) {
         const int qrow = (q0 + 32 * u + r < Q) ? (q0 + 32 * u + r) : (Q - 1);
-        const bf16_t *qp = eq + (int64_t)qrow * D + 8 * h;
+        int qsrc = qrow;
+        if constexpr (COLLECT) qsrc = wave_on ? coll.qmap[qrow] : 0;
+        const bf16_t *qp = eq + (int64_t)qsrc * D + 8 * h;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
         if constexpr (MAXONLY) {   // pre-pass: no thresholds (gthr is null)
@@ -178,6 +197,8 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         } else {
             gt[u] = gthr + qrow;
             thr[u] = import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if constexpr (COLLECT)   // lanes past the last slot hold a copy of it: they must never queue anything
+                if (q0 + 32 * u + r >= Q) thr[u] = INFINITY;
         }
     }
     // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
@@ -252,6 +273,22 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     auto drain = [&](auto uc) __attribute__((always_inline))  {
         constexpr int u = decltype(uc)::value;
         const uint32_t qaddr = qaddr0 + u * (K1_QCAP * 64 * 8);
+        if constexpr (COLLECT) {
+            const int slot = q0 + 32 * u + r;   // lanes past Q never queue (thr = +inf): cnt stays 0 for them
+            const int n = cnt[u];
+            int pos = 0;
+            if (n > 0) pos = atomicAdd(coll.cnt + slot, n);
+#pragma unroll 1
+            for (int p = 0; p < K1_QCAP; ++p) {
+                if (!__any(p < cnt[u])) break;
+                uint64_t e;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(qaddr + p * 512) : "memory");
+                if (p < n && pos + p < coll.cap)   // queue rows are chunk-relative: make them shard rows
+                    coll.buf[(int64_t)slot * coll.cap + pos + p] = e + ((uint64_t)(uint32_t)row0 << 32);
+            }
+            cnt[u] = 0;
+            return;
+        }
 #pragma unroll 1
         for (int p = 0; p < K1_QCAP; ++p) {
             if (!__any(p < cnt[u])) break;
@@ -455,6 +492,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
                 return;
             }
             drain(uc);
+            if constexpr (COLLECT) return;
             if (q0 + 32 * u + r < Q) {
                 const int64_t o = ((int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h) * KL;
 #pragma unroll
@@ -538,41 +576,44 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false>
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false>
 static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                     float *part_s, int *part_i, int *gthr, hipStream_t st) {
+                     float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT>;
+    // the > 64 KiB dynamic-LDS opt-in is per device (a process may drive several GPUs): set it once per device
+    static bool attr_done[64] = {};
+    int dev = 0;
+    TSIM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
         TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
     }
     const int grid = p.nchunks >= 8 ? ((p.nchunks + 7) / 8) * 8 * p.nqb
                                     : 8 * ((p.nqb + (8 / p.nchunks) - 1) / (8 / p.nchunks));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, eq, (int)Q, ec, N, p.rows_per_chunk,
-                       p.nchunks, p.nqb, gthr, part_s, part_i);
+                       p.nchunks, p.nqb, gthr, part_s, part_i, coll);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
 
-template <int KL, bool MAXONLY = false>
+template <int KL, bool MAXONLY = false, bool COLLECT = false>
 static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
-                        float *part_s, int *part_i, int *gthr, hipStream_t st) {
+                        float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     switch (D) {
-        case 128: return launch_k1<128, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 256: return launch_k1<256, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 128: return launch_k1<128, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+        case 256: return launch_k1<256, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 384: {
             static int pair = -1;
             if (pair < 0) { const char *e = getenv("TSIM_K1_PAIR"); pair = e ? atoi(e) : 1; }
-            if (pair && !MAXONLY && KL == 16)
-                return launch_k1<384, 8, 1, KL, MAXONLY, true>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-            return launch_k1<384, 8, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+            if constexpr (!MAXONLY && !COLLECT && KL == 16)
+                if (pair) return launch_k1<384, 8, 1, KL, MAXONLY, true>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+            return launch_k1<384, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         }
-        case 512: return launch_k1<512, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-        case 768: return launch_k1<768, 4, 1, KL, MAXONLY>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
+        case 512: return launch_k1<512, 4, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+        case 768: return launch_k1<768, 4, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
     }
 }
@@ -584,5 +625,8 @@ int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const 
                    float *part_s, int *part_i, int *gthr, hipStream_t st);
 int k1_launch_kl32(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
                    float *part_s, int *part_i, int *gthr, hipStream_t st);
+// widening pass (COLLECT mode) over at most Q slots; defined in k1_collect.hip
+int k1_launch_collect(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N, int *gthr_slots,
+                      K1Collect coll, hipStream_t st);
 
 }  // namespace tsim

@@ -43,25 +43,102 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ 
 }
 
 // =====================================================================================================
-// K2: cos_topk_finalize — one wave per query.
-//   1. select the KL best of the P2*KL partial entries by (MFMA score desc, index asc);
-//   2. re-score them in the canonical order: float64 accumulation over j = 0..D-1, one rounding to f32;
-//   3. order by (canonical score desc, index asc) and emit the first k.
-// Step 2 is what makes results independent of MFMA summation order, tiling and shard count.
+// Exact scores.  Two definitions, both evaluated in float64 in ONE canonical order and rounded once to float32, so that
+// GPU and oracle agree bit for bit (oracle/search_ref._lane_sum): lane l accumulates the products of elements j = l,
+// l + 64, ... in that order (fma of an exact product == multiply + add), then an xor butterfly 32, 16, .., 1.
+//   COS = true  (float32 rows): the reference's score, F.cosine_similarity of the float32 embeddings
+//                /root/reference/src/pipeline/search_pipeline.py:76-77: x.y / (max(|x|, eps) * max(|y|, eps))
+//                (oracle/search_ref.exact_cosine);
+//   COS = false (unit rows as stored): the inner product of the stored unit rows (oracle/search_ref.canonical_scores).
+// MFMA scores only SELECT candidates; every score that is returned or compared for the final order is one of these.
 // =====================================================================================================
+constexpr int XS_MAXI = 12;   // 64 * 12 = 768 elements per row at most
+constexpr double XS_EPS = (double)1e-8f;
+
+template <typename T>
+struct ExactQuery {
+    double v[XS_MAXI];   // this lane's elements j = lane + 64 i of the query row (0 beyond d)
+    double norm;         // COS: max(|q|, eps)
+};
+
+template <typename T, bool COS>
+__device__ __forceinline__ void exact_load_query(ExactQuery<T> &q, const T *row, int d, int lane) {
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < XS_MAXI; ++i) {
+        const int j = lane + 64 * i;
+        q.v[i] = j < d ? (double)load_as_f32<T>(row + j) : 0.0;
+        ss = fma(q.v[i], q.v[i], ss);
+    }
+    q.norm = 1.0;
+    if constexpr (COS) q.norm = fmax(sqrt(wave_sum_f64(ss)), XS_EPS);
+}
+
+// exact score of the query against one row (all 64 lanes take part and get the same value)
+template <typename T, bool COS>
+__device__ __forceinline__ float exact_score(const ExactQuery<T> &q, const T *row, int d, int lane) {
+    double dot = 0.0, cc = 0.0;
+#pragma unroll
+    for (int i = 0; i < XS_MAXI; ++i) {
+        const int j = lane + 64 * i;
+        if (64 * i < d) {   // wave-uniform
+            const double c = j < d ? (double)load_as_f32<T>(row + j) : 0.0;
+            dot = fma(q.v[i], c, dot);
+            if constexpr (COS) cc = fma(c, c, cc);
+        }
+    }
+    dot = wave_sum_f64(dot);
+    if constexpr (COS) {
+        const double nc = fmax(sqrt(wave_sum_f64(cc)), XS_EPS);
+        return (float)(dot / (q.norm * nc));
+    }
+    return (float)dot;
+}
+
 __device__ __forceinline__ bool key_before(float s1, int i1, float s2, int i2) {
     // true if (s1,i1) ranks strictly ahead of (s2,i2)
     return s1 > s2 || (s1 == s2 && i1 < i2);
 }
+__device__ __forceinline__ float float_below(float f) {   // the next float towards -inf (finite f)
+    if (f == 0.f) return -1.17549435e-38f;
+    const int b = __float_as_int(f);
+    return __int_as_float(f > 0.f ? b - 1 : b + 1);
+}
 
-template <int KL>
+// control words of one search call (zeroed on the stream before the first kernel)
+enum { CTL_NFLAG = 0, CTL_NUNRES = 1, CTL_WORDS = 4 };
+// per-query status written to out_status (all results are exact; the status says which pass produced them)
+enum { ST_PASS1 = 0, ST_WIDENED = 1, ST_BRUTE = 2 };
+
+struct GuardArgs {
+    float c1;          // eps = max(c1 * largest |MFMA score - exact score| seen for the query, floor)
+    float floor;
+    int *ctl;          // CTL_* words
+    int *flag_q;       // [Q] flagged queries, compact
+    int *flag_thr;     // [Q] per slot: collection threshold as an ordered int (k1_topk.h float_to_ordered)
+    int *unres_q;      // [Q] queries left to the brute-force pass, compact
+    int *status;       // [Q] or null
+};
+
+// =====================================================================================================
+// K2: cos_topk_finalize — one wave per query.
+//   1. select the KL best of the P2*KL partial entries by (MFMA score desc, index asc);
+//   2. re-score them exactly (above);
+//   3. order by (exact score desc, index asc) and emit the first k;
+//   4. GUARD: every row outside the KL candidates has an MFMA score <= cut = the KL-th selected one, hence an exact
+//      score <= cut + eps when eps bounds |MFMA - exact| for the query.  eps is estimated from the candidates themselves
+//      (c1 x the largest difference observed, never below `floor`).  If cut + eps < the k-th exact score nothing outside
+//      can reach the list and the result stands; otherwise the query is FLAGGED: the widening pass (K1 in COLLECT mode)
+//      gathers every row whose MFMA score exceeds (k-th exact score - eps) and widen_finalize re-scores all of them.
+// =====================================================================================================
+template <int KL, typename T, bool COS>
 __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__restrict__ part_s,
                                                                 const int *__restrict__ part_i, int P2,
-                                                                int64_t Q, const bf16_t *__restrict__ eq,
-                                                                const bf16_t *__restrict__ ec, int D, int k,
+                                                                int64_t Q, int64_t N, const T *__restrict__ xq, int64_t ldq,
+                                                                const T *__restrict__ xc, int64_t ldc, int d, int k,
                                                                 float *__restrict__ out_s,
                                                                 int64_t *__restrict__ out_i,
-                                                                int64_t idx_offset) {
+                                                                int64_t idx_offset, GuardArgs g) {
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -140,29 +217,23 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
             li[KL - 1] = 0x7fffffff;
         }
     }
-    (void)my_s;
+    const int nvalid = __popcll(__ballot(my_i >= 0));   // candidates sit in lanes 0 .. nvalid-1
 
-    // canonical re-score (lanes holding a candidate)
+    // 2. exact re-score: the wave works on one candidate at a time (coalesced row reads)
+    ExactQuery<T> eqr;
+    exact_load_query<T, COS>(eqr, xq + q * ldq, d, lane);
     float cs = -INFINITY;
-    if (my_i >= 0) {
-        const bf16_t *qp = eq + q * D;
-        const bf16_t *cp = ec + (int64_t)my_i * D;
-        double acc = 0.0;
-        for (int j = 0; j < D; j += 8) {
-            const uint4 qa = *reinterpret_cast<const uint4 *>(qp + j);
-            const uint4 ca = *reinterpret_cast<const uint4 *>(cp + j);
-            const uint32_t qw[4] = {qa.x, qa.y, qa.z, qa.w};
-            const uint32_t cw[4] = {ca.x, ca.y, ca.z, ca.w};
+#pragma unroll 1
+    for (int t0 = 0; t0 < nvalid; t0 += 4) {   // four candidates per step: their row reads overlap
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = fma((double)__uint_as_float(qw[u] << 16), (double)__uint_as_float(cw[u] << 16), acc);
-                acc = fma((double)__uint_as_float(qw[u] & 0xffff0000u),
-                          (double)__uint_as_float(cw[u] & 0xffff0000u), acc);
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u < nvalid ? t0 + u : t0;   // past the end: repeat a valid one, result unused
+            const int ci = __shfl(my_i, t, 64);
+            const float sc = exact_score<T, COS>(eqr, xc + (int64_t)ci * ldc, d, lane);
+            if (lane == t0 + u) cs = sc;
         }
-        cs = (float)acc;
     }
-    // final order among the <= KL candidates: rank by counting
+    // 3. final order among the candidates: rank by counting
     int rank = 0;
     for (int t = 0; t < KL; ++t) {
         const float os = __shfl(cs, t, 64);
@@ -173,12 +244,249 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
         out_s[q * k + rank] = cs;
         out_i[q * k + rank] = (int64_t)my_i + idx_offset;
     }
-    // fewer valid candidates than k: pad
-    int nvalid = __popcll(__ballot(my_i >= 0));
-    if (lane >= nvalid && lane < k) {
+    if (lane >= nvalid && lane < k) {   // fewer valid candidates than k: pad
         out_s[q * k + lane] = -INFINITY;
         out_i[q * k + lane] = -1;
     }
+    // 4. guard
+    bool safe = N <= KL || nvalid < KL;   // every row of the corpus is a candidate
+    float tau = 0.f;
+    if (!safe) {
+        const float err = wave_max(lane < nvalid ? fabsf(my_s - cs) : 0.f);
+        const float eps = fmaxf(g.c1 * err, g.floor);
+        const float cut = __shfl(my_s, KL - 1, 64);
+        const unsigned long long kth = __ballot(lane < nvalid && rank == k - 1);   // k <= KL - 4 < nvalid: exactly one lane
+        const float sk = __shfl(cs, __ffsll((long long)kth) - 1, 64);
+        safe = (double)cut + (double)eps < (double)sk;
+        tau = float_below((float)((double)sk - (double)eps));   // rows at or below tau cannot reach sk (strictly)
+        if ((double)tau + (double)eps >= (double)sk) tau = float_below(tau);   // rounding of the float conversion
+    }
+    if (lane == 0) {
+        if (!safe) {
+            const int slot = atomicAdd(g.ctl + CTL_NFLAG, 1);
+            g.flag_q[slot] = (int)q;
+            g.flag_thr[slot] = float_to_ordered(tau);
+        }
+        if (g.status) g.status[q] = safe ? ST_PASS1 : ST_WIDENED;
+    }
+}
+
+// k rounds of "best entry strictly after the previous winner" over LDS arrays sc/ix[0..n): a 256-thread workgroup.
+// red_s/red_i: 4-entry scratch.  Writes (-inf, -1) when the entries run out.  emit(t, score, row) is called by thread 0.
+template <typename EMIT>
+__device__ __forceinline__ void wg_select_topk(const float *sc, const int *ix, int n, int k, float *red_s, int *red_i,
+                                               EMIT emit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float last_s = INFINITY;
+    int last_i = -1;
+    for (int t = 0; t < k; ++t) {
+        float bs = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const float s = sc[e];
+            const int i = ix[e];
+            if (i >= 0 && key_before(last_s, last_i, s, i) && key_before(s, i, bs, bi)) {
+                bs = s;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (key_before(os, oi, bs, bi)) {
+                bs = os;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            red_s[wave] = bs;
+            red_i[wave] = bi;
+        }
+        __syncthreads();
+        bs = red_s[0];
+        bi = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (key_before(red_s[w], red_i[w], bs, bi)) {
+                bs = red_s[w];
+                bi = red_i[w];
+            }
+        __syncthreads();
+        const bool none = bi == 0x7fffffff;
+        if (threadIdx.x == 0) emit(t, none ? -INFINITY : bs, none ? -1 : bi);
+        if (none) {
+            last_s = -INFINITY;
+            last_i = 0x7fffffff;   // nothing ranks after this: the remaining slots pad
+        } else {
+            last_s = bs;
+            last_i = bi;
+        }
+    }
+}
+
+// =====================================================================================================
+// widen_finalize: one workgroup per FLAGGED query (slot).  Re-scores every entry the widening pass collected for it
+// (every row whose MFMA score exceeded the slot's threshold), selects the exact top-k and repeats the guard with the
+// threshold that was actually used and the errors seen on this larger sample.  An overflowed buffer or a failed guard
+// hands the query to the brute-force pass.
+// =====================================================================================================
+constexpr int COLL_CAP = 1024;   // entries per slot
+
+template <typename T, bool COS>
+__global__ __launch_bounds__(256) void widen_finalize_kernel(const unsigned long long *__restrict__ coll_buf,
+                                                             const int *__restrict__ coll_cnt, int64_t Q, int64_t N,
+                                                             const T *__restrict__ xq, int64_t ldq,
+                                                             const T *__restrict__ xc, int64_t ldc, int d, int k,
+                                                             float *__restrict__ out_s, int64_t *__restrict__ out_i,
+                                                             int64_t idx_offset, GuardArgs g) {
+    __shared__ float sc[COLL_CAP];
+    __shared__ int ix[COLL_CAP];
+    __shared__ float red_s[4];
+    __shared__ int red_i[4];
+    __shared__ float s_err[4];
+    __shared__ float s_top[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int nflag = g.ctl[CTL_NFLAG];
+    nflag = nflag < Q ? nflag : (int)Q;
+    for (int slot = blockIdx.x; slot < nflag; slot += gridDim.x) {
+        const int q = g.flag_q[slot];
+        const int cnt = coll_cnt[slot];
+        const int n = cnt < COLL_CAP ? cnt : COLL_CAP;
+        bool resolved = cnt <= COLL_CAP;
+        if (resolved) {   // workgroup-uniform
+            ExactQuery<T> eqr;
+            exact_load_query<T, COS>(eqr, xq + (int64_t)q * ldq, d, lane);
+            float err = 0.f;
+            for (int e = wave; e < n; e += 4) {
+                const unsigned long long ent = coll_buf[(int64_t)slot * COLL_CAP + e];
+                const int row = (int)(ent >> 32);
+                const float s = exact_score<T, COS>(eqr, xc + (int64_t)row * ldc, d, lane);
+                err = fmaxf(err, fabsf(__uint_as_float((uint32_t)ent) - s));
+                if (lane == 0) {
+                    sc[e] = s;
+                    ix[e] = row;
+                }
+            }
+            if (lane == 0) s_err[wave] = err;
+            __syncthreads();
+            wg_select_topk(sc, ix, n, k, red_s, red_i, [&](int t, float s, int row) {
+                out_s[(int64_t)q * k + t] = s;
+                out_i[(int64_t)q * k + t] = row < 0 ? -1 : (int64_t)row + idx_offset;
+                s_top[t] = s;
+            });
+            __syncthreads();
+            // guard again, with the threshold the collection used (imported one step lower, k1_topk.h import_threshold)
+            // the sample is larger here (every collected row, not KL candidates), so its largest error is a better estimate
+            // of the bound: half the safety factor of the first pass (not below 1)
+            const float errmax = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
+            const float eps = fmaxf(fmaxf(0.5f * g.c1, 1.f) * errmax, g.floor);
+            const float thr = ordered_to_float(g.flag_thr[slot]);
+            resolved = n >= k && (double)thr + (double)eps < (double)s_top[k - 1];
+        }
+        if (threadIdx.x == 0) {
+            if (!resolved) g.unres_q[atomicAdd(g.ctl + CTL_NUNRES, 1)] = q;
+            if (g.status) g.status[q] = resolved ? ST_WIDENED : ST_BRUTE;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// Brute-force exact pass for the queries nothing else resolved: every row of the shard is scored exactly.
+//   bf_partial: workgroup (chunk c, slot u): rows of chunk c in blocks of BF_SB; a running exact top-k per chunk.
+//   bf_merge:   one workgroup per slot merges the NCH chunk lists and writes the query's final list.
+// HBM-bound (N*d*4 bytes per query); last resort, and the serving path for k > 28 on small shards.
+// =====================================================================================================
+constexpr int BF_SB = 2048;
+constexpr int BF_MAXK = 64;
+
+template <typename T, bool COS>
+__global__ __launch_bounds__(256) void bf_partial_kernel(int64_t Q, int64_t N, int rows_per_chunk,
+                                                         const T *__restrict__ xq, int64_t ldq,
+                                                         const T *__restrict__ xc, int64_t ldc, int d, int k,
+                                                         float *__restrict__ bf_s, int *__restrict__ bf_i, GuardArgs g) {
+    __shared__ float sc[BF_SB + BF_MAXK];
+    __shared__ int ix[BF_SB + BF_MAXK];
+    __shared__ float top_s[BF_MAXK];
+    __shared__ int top_i[BF_MAXK];
+    __shared__ float red_s[4];
+    __shared__ int red_i[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = gridDim.x, chunk = blockIdx.x;
+    int nu = g.ctl[CTL_NUNRES];
+    nu = nu < Q ? nu : (int)Q;
+    const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < N ? r0 + rows_per_chunk : N;
+    for (int u = blockIdx.y; u < nu; u += gridDim.y) {
+        const int q = g.unres_q[u];
+        ExactQuery<T> eqr;
+        exact_load_query<T, COS>(eqr, xq + (int64_t)q * ldq, d, lane);
+        if (threadIdx.x < BF_MAXK) {
+            top_s[threadIdx.x] = -INFINITY;
+            top_i[threadIdx.x] = -1;
+        }
+        __syncthreads();
+        for (int64_t b = r0; b < r1; b += BF_SB) {
+            const int nb = (int)(r1 - b < BF_SB ? r1 - b : BF_SB);
+            for (int e = wave; e < nb; e += 4) {
+                const float s = exact_score<T, COS>(eqr, xc + (b + e) * ldc, d, lane);
+                if (lane == 0) {
+                    sc[e] = s;
+                    ix[e] = (int)(b + e);
+                }
+            }
+            if (threadIdx.x < k) {   // the running list competes with the new block
+                sc[nb + threadIdx.x] = top_s[threadIdx.x];
+                ix[nb + threadIdx.x] = top_i[threadIdx.x];
+            }
+            __syncthreads();
+            wg_select_topk(sc, ix, nb + k, k, red_s, red_i, [&](int t, float s, int row) {
+                top_s[t] = s;
+                top_i[t] = row;
+            });
+            __syncthreads();
+        }
+        if (threadIdx.x < k) {
+            bf_s[((int64_t)u * nch + chunk) * k + threadIdx.x] = top_s[threadIdx.x];
+            bf_i[((int64_t)u * nch + chunk) * k + threadIdx.x] = top_i[threadIdx.x];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bf_merge_kernel(int64_t Q, int nch, int k, const float *__restrict__ bf_s,
+                                                       const int *__restrict__ bf_i, float *__restrict__ out_s,
+                                                       int64_t *__restrict__ out_i, int64_t idx_offset, GuardArgs g) {
+    __shared__ float red_s[4];
+    __shared__ int red_i[4];
+    int nu = g.ctl[CTL_NUNRES];
+    nu = nu < Q ? nu : (int)Q;
+    for (int u = blockIdx.x; u < nu; u += gridDim.x) {
+        const int q = g.unres_q[u];
+        wg_select_topk(bf_s + (int64_t)u * nch * k, bf_i + (int64_t)u * nch * k, nch * k, k, red_s, red_i,
+                       [&](int t, float s, int row) {
+                           out_s[(int64_t)q * k + t] = s;
+                           out_i[(int64_t)q * k + t] = row < 0 ? -1 : (int64_t)row + idx_offset;
+                       });
+        if (threadIdx.x == 0 && g.status) g.status[q] = ST_BRUTE;
+    }
+}
+
+// every query goes to the widening pass with the threshold found by thr_select minus `margin` (k > 28), or straight to
+// the brute-force pass (all_brute)
+__global__ void flag_all_kernel(int64_t Q, const int *__restrict__ gthr, float margin, bool all_brute, GuardArgs g) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q == 0) g.ctl[all_brute ? CTL_NUNRES : CTL_NFLAG] = (int)Q;
+    if (q >= Q) return;
+    if (all_brute) {
+        g.unres_q[q] = (int)q;
+    } else {
+        g.flag_q[q] = (int)q;
+        const int key = gthr[q];
+        g.flag_thr[q] = key <= K1_GTHR_INIT ? key : float_to_ordered(ordered_to_float(key) - margin);
+    }
+    if (g.status) g.status[q] = all_brute ? ST_BRUTE : ST_WIDENED;
 }
 
 // =====================================================================================================
@@ -393,69 +701,250 @@ extern "C" void tsim_time_next_topk(void *start_event, void *stop_event) {
     g_ev_stop = reinterpret_cast<hipEvent_t>(stop_event);
 }
 
+namespace tsim {
+constexpr int TOPK_MAX_LISTS = 28;   // largest k the list kernels (KL = 32) serve
+constexpr int TOPK_MAX_K = BF_MAXK;  // largest k at all (widening / brute-force passes)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Workspace layout of one search call (byte offsets).
+struct SearchWs {
+    size_t part_s, part_i, gthr, bmax, ctl, flag_q, flag_thr, unres_q, coll_cnt, coll_buf, bf_s, bf_i, total;
+    int bf_nch, bf_rows;
+};
+
+static void plan_workspace(int64_t Q, int64_t N, int k, SearchWs *w) {
+    size_t part = 0;
+    if (k <= TOPK_MAX_LISTS) {   // the plan depends on the padded width only through the wave count: take the larger layout
+        TopkPlan a, b;
+        plan_topk(Q, N, 384, k, &a);
+        plan_topk(Q, N, 768, k, &b);
+        part = a.part_elems > b.part_elems ? a.part_elems : b.part_elems;
+    }
+    int nch = (int)((N + 255) / 256);
+    w->bf_nch = nch < 64 ? (nch < 1 ? 1 : nch) : 64;
+    w->bf_rows = (int)((N + w->bf_nch - 1) / w->bf_nch);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align256(bytes); return at; };
+    w->part_s = take(part * 4);
+    w->part_i = take(part * 4);
+    w->gthr = take((size_t)Q * 4);
+    w->bmax = take((size_t)Q * K1_PREPASS_MAX_P2 * 4);
+    w->ctl = take(CTL_WORDS * 4);
+    w->flag_q = take((size_t)Q * 4);
+    w->flag_thr = take((size_t)Q * 4);
+    w->unres_q = take((size_t)Q * 4);
+    w->coll_cnt = take((size_t)Q * 4);
+    w->coll_buf = take((size_t)Q * COLL_CAP * 8);
+    w->bf_s = take((size_t)Q * w->bf_nch * k * 4);
+    w->bf_i = take((size_t)Q * w->bf_nch * k * 4);
+    w->total = o;
+}
+
+// plan of the widening pass: enough chunks that ONE flagged query block still spreads over the chip
+static void plan_collect(int64_t Q, int64_t N, int D, TopkPlan *p) {
+    plan_topk(Q, N, D, 1, p);
+    int64_t nch = 128, max_ch = (N + 255) / 256;
+    if (nch > max_ch) nch = max_ch;
+    if (nch < 8) {   // the kernel's block map wants 1, 2, 4 or >= 8 chunks
+        int p2 = 1;
+        while (p2 * 2 <= nch) p2 *= 2;
+        nch = p2;
+    }
+    int64_t rpc = (N + nch - 1) / nch;
+    rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;
+    p->rows_per_chunk = (int)rpc;
+    p->nchunks = (int)((N + rpc - 1) / rpc);
+    if (p->nchunks < 8 && (p->nchunks & (p->nchunks - 1))) {   // rounding produced 3, 5, 6 or 7 chunks: use fewer, longer ones
+        int p2 = 1;
+        while (p2 * 2 <= p->nchunks) p2 *= 2;
+        rpc = (N + p2 - 1) / p2;
+        rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;
+        p->rows_per_chunk = (int)rpc;
+        p->nchunks = (int)((N + rpc - 1) / rpc);
+    }
+    p->P2 = p->nchunks * 2;
+}
+
+// block maxima over the WHOLE shard in >= 2*kneed partitions (k > 28: the kneed-th largest block maximum is a lower bound
+// of the kneed-th best MFMA score); false when the shard is too small for that many partitions
+static bool plan_fullmax(int64_t Q, int64_t N, int D, int kneed, TopkPlan *p) {
+    plan_topk(Q, N, D, 1, p);
+    int64_t nch = 512 / p->nqb;
+    if (nch < kneed) nch = kneed;            // P2 = 2 nch >= 2 kneed
+    if (nch > K1_PREPASS_MAX_P2 / 2) nch = K1_PREPASS_MAX_P2 / 2;
+    int64_t rpc = (N + nch - 1) / nch;
+    rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;
+    p->rows_per_chunk = (int)rpc;
+    p->nchunks = (int)((N + rpc - 1) / rpc);
+    p->P2 = p->nchunks * 2;
+    p->part_elems = (size_t)Q * p->P2;
+    // every partition (a lane half of a chunk: rows 4h..4h+3 of each group of 8) must hold at least one row
+    return p->nchunks >= 8 && p->P2 >= kneed && p->P2 <= K1_PREPASS_MAX_P2 && N - (int64_t)(p->nchunks - 1) * rpc >= 8;
+}
+
+static float guard_c1() {
+    static float c1 = -1.f;
+    if (c1 < 0.f) { const char *e = getenv("TSIM_GUARD_C1"); c1 = e ? (float)atof(e) : 4.0f; if (!(c1 >= 1.f)) c1 = 1.f; }
+    return c1;
+}
+
+template <typename T, bool COS>
+static int search_tail(const SearchWs &w, char *ws, int64_t Q, int64_t N, const bf16_t *eq, const bf16_t *ec, int ld,
+                       const T *xq, int64_t ldq, const T *xc, int64_t ldc, int d, int k, float *out_s, int64_t *out_i,
+                       int64_t idx_offset, const GuardArgs &g, bool run_collect, hipStream_t st) {
+    // widening pass + its finalisation (workgroups leave at once when nothing was flagged) ...
+    if (run_collect) {
+        TopkPlan cp;
+        plan_collect(Q, N, ld, &cp);
+        K1Collect coll;
+        coll.qcount = g.ctl + CTL_NFLAG;
+        coll.qmap = g.flag_q;
+        coll.buf = reinterpret_cast<unsigned long long *>(ws + w.coll_buf);
+        coll.cnt = reinterpret_cast<int *>(ws + w.coll_cnt);
+        coll.cap = COLL_CAP;
+        int rc = k1_launch_collect(cp, ld, eq, Q, ec, N, g.flag_thr, coll, st);
+        if (rc) return rc;
+        const unsigned wg = (unsigned)(Q < 2048 ? Q : 2048);
+        hipLaunchKernelGGL((widen_finalize_kernel<T, COS>), dim3(wg), dim3(256), 0, st, coll.buf, coll.cnt, Q, N, xq, ldq, xc,
+                           ldc, d, k, out_s, out_i, idx_offset, g);
+        TSIM_HIP_CHECK(hipGetLastError());
+    }
+    // ... and the brute-force pass for whatever is still unresolved
+    float *bf_s = reinterpret_cast<float *>(ws + w.bf_s);
+    int *bf_i = reinterpret_cast<int *>(ws + w.bf_i);
+    const unsigned us = (unsigned)(Q < 64 ? Q : 64);
+    hipLaunchKernelGGL((bf_partial_kernel<T, COS>), dim3(w.bf_nch, us), dim3(256), 0, st, Q, N, w.bf_rows, xq, ldq, xc, ldc, d, k,
+                       bf_s, bf_i, g);
+    TSIM_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(bf_merge_kernel, dim3((unsigned)(Q < 1024 ? Q : 1024)), dim3(256), 0, st, Q, w.bf_nch, k, bf_s, bf_i,
+                       out_s, out_i, idx_offset, g);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
+template <int KL, typename T, bool COS>
+static void launch_finalize(const TopkPlan &p, const float *part_s, const int *part_i, int64_t Q, int64_t N, const T *xq,
+                            int64_t ldq, const T *xc, int64_t ldc, int d, int k, float *out_s, int64_t *out_i,
+                            int64_t idx_offset, const GuardArgs &g, hipStream_t st) {
+    hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, part_s, part_i,
+                       p.P2, Q, N, xq, ldq, xc, ldc, d, k, out_s, out_i, idx_offset, g);
+}
+}  // namespace tsim
+
 extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) {
-    if (Q <= 0 || N <= 0 || k <= 0 || k > 28) return 0;
-    // the plan depends on the padded width only through the wave count; take the larger (4-wave) layout
-    TopkPlan a, b;
-    plan_topk(Q, N, 384, k, &a);
-    plan_topk(Q, N, 768, k, &b);
-    const size_t e = a.part_elems > b.part_elems ? a.part_elems : b.part_elems;
-    return e * 8 + (size_t)Q * 4 + (size_t)Q * K1_PREPASS_MAX_P2 * 4 + 256;
+    if (Q <= 0 || N <= 0 || k <= 0 || k > TOPK_MAX_K) return 0;
+    SearchWs w;
+    plan_workspace(Q, N, k, &w);
+    return w.total;
+}
+
+extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t ldq_f32, int64_t Q, const void *ec,
+                                   const float *ec_f32, int64_t ldc_f32, int64_t N, int d, int ld, int k,
+                                   float *out_scores, int64_t *out_idx, int32_t *out_status, int64_t idx_offset,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    TSIM_REQUIRE(eq && ec && out_scores && out_idx, "cosine_topk: null pointer");
+    TSIM_REQUIRE(Q > 0 && N > 0, "cosine_topk: empty input Q=%lld N=%lld", (long long)Q, (long long)N);
+    TSIM_REQUIRE(k >= 1 && k <= TOPK_MAX_K, "cosine_topk: k=%d outside 1..%d", k, TOPK_MAX_K);
+    TSIM_REQUIRE(N < (1ll << 31) - 64 && Q < (1ll << 31) - 512, "cosine_topk: shard too large for 32-bit row ids");
+    TSIM_REQUIRE(ld == tsim_pad_dim(d) && ld > 0, "cosine_topk: rows must be padded to tsim_pad_dim(d)=%d (got ld=%d)",
+                 tsim_pad_dim(d), ld);
+    TSIM_REQUIRE((((uintptr_t)eq | (uintptr_t)ec) & 15) == 0, "cosine_topk: embedding matrices must be 16-byte aligned");
+    TSIM_REQUIRE((eq_f32 == nullptr) == (ec_f32 == nullptr), "cosine_topk: pass both float32 matrices or neither");
+    const bool cosf = eq_f32 != nullptr;
+    if (cosf) TSIM_REQUIRE(ldq_f32 >= d && ldc_f32 >= d, "cosine_topk: float32 row strides %lld/%lld < d=%d", (long long)ldq_f32,
+                           (long long)ldc_f32, d);
+    SearchWs w;
+    plan_workspace(Q, N, k, &w);
+    if (!workspace || workspace_bytes < w.total)
+        return fail(TSIM_ENOMEM, "cosine_topk: workspace %zu B < %zu B", workspace_bytes, w.total);
+    char *ws = reinterpret_cast<char *>(workspace);
+    float *part_s = reinterpret_cast<float *>(ws + w.part_s);
+    int *part_i = reinterpret_cast<int *>(ws + w.part_i);
+    int *gthr = reinterpret_cast<int *>(ws + w.gthr);   // per-query shared threshold words, re-initialised every call
+    float *bmax = reinterpret_cast<float *>(ws + w.bmax);
+    hipStream_t st = as_stream(stream);
+    const bf16_t *uq = (const bf16_t *)eq, *uc = (const bf16_t *)ec;
+
+    GuardArgs g;
+    g.c1 = guard_c1();
+    // floor of the error bound: float32 accumulation of d products of unit rows (d * 2^-24, rigorous for unit rows)
+    g.floor = (float)ld * 5.9604645e-8f;
+    g.ctl = reinterpret_cast<int *>(ws + w.ctl);
+    g.flag_q = reinterpret_cast<int *>(ws + w.flag_q);
+    g.flag_thr = reinterpret_cast<int *>(ws + w.flag_thr);
+    g.unres_q = reinterpret_cast<int *>(ws + w.unres_q);
+    g.status = out_status;
+    // ctl .. coll_cnt are contiguous: one memset clears the control words and the per-slot counters
+    TSIM_HIP_CHECK(hipMemsetAsync(ws + w.ctl, 0, w.coll_cnt + align256((size_t)Q * 4) - w.ctl, st));
+
+    bool run_collect = true;
+    if (k <= TOPK_MAX_LISTS) {
+        TopkPlan p, pp;
+        plan_topk(Q, N, ld, k, &p);
+        static int prepass_on = -1;
+        if (prepass_on < 0) { const char *e = getenv("TSIM_K1_PREPASS"); prepass_on = e ? atoi(e) : 1; }
+        if (prepass_on && plan_prepass(Q, N, p, &pp)) {
+            // threshold pre-pass: block maxima over the first rows, KL-th largest per query -> initial shared bounds
+            const int64_t S = (int64_t)pp.nchunks * pp.rows_per_chunk;
+            int rc0 = k1_launch_blockmax(pp, ld, uq, Q, uc, S, bmax, st);
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, pp.P2, Q, p.KL, gthr);
+            TSIM_HIP_CHECK(hipGetLastError());
+        } else {
+            TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
+        }
+#ifdef TSIM_PP_STAMPS
+        if (getenv("TSIM_K1_DIAG_NOSEL"))   // DIAGNOSTIC: thresholds nothing can pass (results are wrong): the time without selection
+            TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, (size_t)Q * 4, st));
+#endif
+        hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
+        g_ev_start = g_ev_stop = nullptr;
+        if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));
+        int rc = p.KL == 16 ? k1_launch_kl16(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st)
+                            : k1_launch_kl32(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st);
+        if (rc) return rc;
+        if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
+        if (cosf) {
+            if (p.KL == 16) launch_finalize<16, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k,
+                                                             out_scores, out_idx, idx_offset, g, st);
+            else launch_finalize<32, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, out_scores,
+                                                  out_idx, idx_offset, g, st);
+        } else {
+            if (p.KL == 16) launch_finalize<16, bf16_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores,
+                                                               out_idx, idx_offset, g, st);
+            else launch_finalize<32, bf16_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores, out_idx,
+                                                    idx_offset, g, st);
+        }
+        TSIM_HIP_CHECK(hipGetLastError());
+    } else {
+        // k > 28: no list kernel.  Block maxima over the whole shard give a lower bound of the k-th best MFMA score; every row
+        // above (bound - margin) is collected and re-scored; widen_finalize's guard decides whether that was enough.
+        TopkPlan fp;
+        const bool ok = plan_fullmax(Q, N, ld, k, &fp);
+        if (ok) {
+            int rc0 = k1_launch_blockmax(fp, ld, uq, Q, uc, N, bmax, st);
+            if (rc0) return rc0;
+            hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, fp.P2, Q, k, gthr);
+            TSIM_HIP_CHECK(hipGetLastError());
+        }
+        const float margin = cosf ? 4e-3f : 2.f * g.floor;   // prior for 2 eps; the guard re-checks with measured errors
+        hipLaunchKernelGGL(flag_all_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, Q, gthr, margin, !ok, g);
+        TSIM_HIP_CHECK(hipGetLastError());
+        run_collect = ok;
+    }
+    if (cosf)
+        return search_tail<float, true>(w, ws, Q, N, uq, uc, ld, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, out_scores, out_idx,
+                                        idx_offset, g, run_collect, st);
+    return search_tail<bf16_t, false>(w, ws, Q, N, uq, uc, ld, uq, ld, uc, ld, ld, k, out_scores, out_idx, idx_offset, g,
+                                      run_collect, st);
 }
 
 extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64_t N, int d, int ld, int k,
                                 float *out_scores, int64_t *out_idx, int64_t idx_offset, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    TSIM_REQUIRE(eq && ec && out_scores && out_idx, "cosine_topk: null pointer");
-    TSIM_REQUIRE(Q > 0 && N > 0, "cosine_topk: empty input Q=%lld N=%lld", (long long)Q, (long long)N);
-    TSIM_REQUIRE(k >= 1 && k <= 28, "cosine_topk: k=%d outside 1..28", k);
-    TSIM_REQUIRE(N < (1ll << 31) - 64 && Q < (1ll << 31) - 512, "cosine_topk: shard too large for 32-bit row ids");
-    TSIM_REQUIRE(ld == tsim_pad_dim(d) && ld > 0, "cosine_topk: rows must be padded to tsim_pad_dim(d)=%d (got ld=%d)",
-                 tsim_pad_dim(d), ld);
-    TSIM_REQUIRE((((uintptr_t)eq | (uintptr_t)ec) & 15) == 0, "cosine_topk: embedding matrices must be 16-byte aligned");
-    TopkPlan p;
-    plan_topk(Q, N, ld, k, &p);
-    const size_t need = p.part_elems * 8 + (size_t)Q * 4 + (size_t)Q * K1_PREPASS_MAX_P2 * 4;
-    if (!workspace || workspace_bytes < need)
-        return fail(TSIM_ENOMEM, "cosine_topk: workspace %zu B < %zu B", workspace_bytes, need);
-    float *part_s = reinterpret_cast<float *>(workspace);
-    int *part_i = reinterpret_cast<int *>(part_s + p.part_elems);
-    int *gthr = part_i + p.part_elems;   // per-query shared threshold words, re-initialised every call
-    float *bmax = reinterpret_cast<float *>(gthr + Q);
-    hipStream_t st = as_stream(stream);
-    TopkPlan pp;
-    static int prepass_on = -1;
-    if (prepass_on < 0) { const char *e = getenv("TSIM_K1_PREPASS"); prepass_on = e ? atoi(e) : 1; }
-    if (prepass_on && plan_prepass(Q, N, p, &pp)) {
-        // threshold pre-pass: block maxima over the first rows, KL-th largest per query -> initial shared bounds
-        const int64_t S = (int64_t)pp.nchunks * pp.rows_per_chunk;
-        int rc0 = k1_launch_blockmax(pp, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, S, bmax, st);
-        if (rc0) return rc0;
-        hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, pp.P2, Q, p.KL, gthr);
-        TSIM_HIP_CHECK(hipGetLastError());
-    } else {
-        TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
-    }
-#ifdef TSIM_PP_STAMPS
-    if (getenv("TSIM_K1_DIAG_NOSEL"))   // DIAGNOSTIC: thresholds nothing can pass (results are wrong): the time without selection
-        TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, (size_t)Q * 4, st));
-#endif
-    hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
-    g_ev_start = g_ev_stop = nullptr;
-    if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));
-    int rc = p.KL == 16 ? k1_launch_kl16(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, gthr, st)
-                        : k1_launch_kl32(p, ld, (const bf16_t *)eq, Q, (const bf16_t *)ec, N, part_s, part_i, gthr, st);
-    if (rc) return rc;
-    if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
-    const unsigned grid = (unsigned)((Q + 3) / 4);
-    if (p.KL == 16)
-        hipLaunchKernelGGL(cos_topk_finalize_kernel<16>, dim3(grid), dim3(256), 0, st, part_s, part_i, p.P2, Q,
-                           (const bf16_t *)eq, (const bf16_t *)ec, ld, k, out_scores, out_idx, idx_offset);
-    else
-        hipLaunchKernelGGL(cos_topk_finalize_kernel<32>, dim3(grid), dim3(256), 0, st, part_s, part_i, p.P2, Q,
-                           (const bf16_t *)eq, (const bf16_t *)ec, ld, k, out_scores, out_idx, idx_offset);
-    TSIM_HIP_CHECK(hipGetLastError());
-    return TSIM_OK;
+    return tsim_cosine_topk_ex(eq, nullptr, 0, Q, ec, nullptr, 0, N, d, ld, k, out_scores, out_idx, nullptr, idx_offset,
+                               workspace, workspace_bytes, stream);
 }
 
 extern "C" int tsim_topk_merge(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in, int k_out,

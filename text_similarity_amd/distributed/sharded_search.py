@@ -2,12 +2,17 @@
 over xGMI on ROCm).  The reference has no multi-device code at all; this is the scale-out of
 ``SentenceMiningPipeline._search`` (/root/reference/src/pipeline/search_pipeline.py:60-89) for BASELINE.json config 4.
 
-Partitioning: rank r owns corpus rows [offset_r, offset_r + n_r) as unit bf16 rows resident in its HBM; the
-corpus never moves.  Per query batch there are exactly two exchanges, both tiny and latency-bound:
-  1. all-gather of the query unit rows   [Q_local, ld] bf16 per rank  -> [Q, ld] everywhere
-  2. all-gather of per-shard candidates  [Q, k] (score f32, global index i64) per rank
-followed by a k-way merge with the global tie rule (score desc, index asc), so the result is bit-identical to a
-single-GPU search over the concatenated corpus (tests/test_sharded_cpu.py, world_size 2 over gloo).
+Partitioning: rank r owns corpus rows [offset_r, offset_r + n_r) — the float32 embeddings and their unit bf16 rows,
+resident in its HBM; the corpus never moves.  Per query batch there are exactly two exchanges, both tiny and
+latency-bound:
+  1. all-gather of the query embeddings   [Q_local, d] float32 per rank  -> [Q, d] everywhere (unit rows are made locally)
+  2. all-gather of per-shard candidates   [Q, k] (score f32, global index i64) per rank, ONE packed buffer
+followed by a k-way merge with the global tie rule (score desc, index asc).  Every shard returns the exact top-k of its
+rows with exact scores, so the result is bit-identical to a single-GPU search over the concatenated corpus
+(tests/test_sharded_cpu.py, world_size 2 over gloo; tests/test_sharded_gpu.py with the HIP kernels).
+
+``submit`` / ``finish`` split a search at the first exchange: ``submit`` starts the query all-gather of batch i+1 on a side
+stream while the local search of batch i still runs on the main stream; ``search`` = ``finish(submit)``.
 
 ``local_search`` / ``merge`` are injectable so that the collective choreography can be exercised on CPU ranks
 (gloo) with the oracle standing in for the kernels — in tests only; the defaults are the HIP ops and raise without
@@ -15,18 +20,21 @@ a GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Iterable, Iterator, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def _hip_local_search(q_unit, c_unit, d, k, offset):
+def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset):
     from .. import ops
-    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset)
+    if c_f32 is None:                       # unit rows only: q_f32 holds unit bf16 rows
+        return ops.cosine_topk(q_f32, c_unit, d, k, idx_offset=offset)
+    q_unit = ops.l2norm_rows(q_f32)
+    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32)
 
 
-def _hip_merge(scores: List[torch.Tensor], idx: List[torch.Tensor], k: int):
+def _hip_merge(scores: torch.Tensor, idx: torch.Tensor, k: int):
     from .. import ops
     return ops.topk_merge(scores, idx, k)
 
@@ -38,11 +46,22 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class _Ticket:
+    __slots__ = ("q_all", "event")
+
+    def __init__(self, q_all, event):
+        self.q_all, self.event = q_all, event
+
+
 class ShardedCorpusSearch:
     def __init__(self, corpus_unit_local: torch.Tensor, d: int, row_offset: int,
                  group: Optional[dist.ProcessGroup] = None,
-                 local_search: Callable = _hip_local_search, merge: Callable = _hip_merge):
+                 local_search: Callable = _hip_local_search, merge: Callable = _hip_merge,
+                 corpus_f32_local: Optional[torch.Tensor] = None):
+        """``corpus_f32_local`` [n_r, d] float32: the embeddings (scores are then the reference's cosines of float32 rows and
+        queries are passed as float32 embeddings); without it queries are unit bf16 rows and scores their inner products."""
         self.corpus = corpus_unit_local
+        self.corpus_f32 = corpus_f32_local
         self.d = int(d)
         self.row_offset = int(row_offset)
         self.group = group
@@ -50,6 +69,7 @@ class ShardedCorpusSearch:
         self.merge = merge
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self._comm_stream = None
 
     def _all_gather(self, out: torch.Tensor, src: torch.Tensor) -> None:
         """all_gather_into_tensor; with the gloo backend (CPU rehearsals of the multi-GPU path, e.g. two ranks sharing
@@ -61,27 +81,68 @@ class ShardedCorpusSearch:
         else:
             dist.all_gather_into_tensor(out, src, group=self.group)
 
-    def gather_queries(self, q_unit_local: torch.Tensor) -> torch.Tensor:
-        """all-gather of equally sized query slices: [Q_local, ld] -> [world*Q_local, ld] (rank-major)."""
+    def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
+        """all-gather of equally sized query slices: [Q_local, w] -> [world*Q_local, w] (rank-major); float32 embeddings or
+        unit bf16 rows."""
         if self.world == 1:
-            return q_unit_local
-        # bf16 travels as raw bytes so that the gloo test backend (no bf16/int16 support) runs the same code
-        src = q_unit_local.contiguous().view(torch.uint8)
+            return q_local
+        # rows travel as raw bytes so that the gloo test backend (no bf16 support) runs the same code
+        src = q_local.contiguous().view(torch.uint8)
         out = torch.empty((self.world * src.shape[0], src.shape[1]), dtype=torch.uint8, device=src.device)
         self._all_gather(out, src)
-        return out.view(torch.bfloat16)
+        return out.view(q_local.dtype)
 
-    def search(self, q_unit_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Every rank passes its slice of the query batch and gets (scores [Q,k], global indices [Q,k]) for ALL
-        queries (rank-major order)."""
-        q_all = self.gather_queries(q_unit_local)
-        s, i = self.local_search(q_all, self.corpus, self.d, k, self.row_offset)
+    # ------------------------------------------------------------------ two-stage API
+    def submit(self, q_local: torch.Tensor) -> _Ticket:
+        """Start exchange 1 for a batch.  On a GPU it runs on a side stream ordered after the work already queued on the
+        current stream (the encoder that produced ``q_local``), so it overlaps whatever the caller enqueues next."""
+        if self.world == 1 or not q_local.is_cuda:
+            return _Ticket(self.gather_queries(q_local), None)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=q_local.device)
+        main = torch.cuda.current_stream(q_local.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ready)
+            q_all = self.gather_queries(q_local)
+            done = torch.cuda.Event()
+            done.record(self._comm_stream)
+        q_local.record_stream(self._comm_stream)
+        return _Ticket(q_all, done)
+
+    def finish(self, ticket: _Ticket, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Local search of the gathered batch, exchange 2 (one packed buffer) and the merge: (scores [Q,k], global indices
+        [Q,k]) for ALL queries (rank-major order), on every rank."""
+        q_all = ticket.q_all
+        if ticket.event is not None:
+            torch.cuda.current_stream(q_all.device).wait_event(ticket.event)
+            q_all.record_stream(torch.cuda.current_stream(q_all.device))
+        s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset)
         if self.world == 1:
             return s, i
         Q = s.shape[0]
-        s_cat = torch.empty((self.world * Q, k), dtype=s.dtype, device=s.device)
-        i_cat = torch.empty((self.world * Q, k), dtype=i.dtype, device=i.device)
-        self._all_gather(s_cat, s.contiguous())
-        self._all_gather(i_cat, i.contiguous())
-        s_all, i_all = s_cat.view(self.world, Q, k), i_cat.view(self.world, Q, k)
-        return self.merge([s_all[r] for r in range(self.world)], [i_all[r] for r in range(self.world)], k)
+        # one buffer per rank: [Q, 3k] int32 = score bits | index (lo, hi)
+        packed = torch.cat([s.contiguous().view(torch.int32), i.contiguous().view(torch.int32).view(Q, 2 * k)], dim=1)
+        gathered = torch.empty((self.world * Q, 3 * k), dtype=torch.int32, device=packed.device)
+        self._all_gather(gathered, packed)
+        gathered = gathered.view(self.world, Q, 3 * k)
+        s_all = gathered[:, :, :k].contiguous().view(torch.float32)
+        i_all = gathered[:, :, k:].contiguous().view(torch.int64)
+        return self.merge(s_all, i_all, k)
+
+    def search(self, q_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Every rank passes its slice of the query batch and gets the merged result for ALL queries."""
+        return self.finish(self.submit(q_local), k)
+
+    def search_stream(self, query_batches: Iterable[torch.Tensor], k: int) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        """Software pipeline over a sequence of batches: the query all-gather of batch i+1 is in flight while batch i is
+        searched.  ``query_batches`` may be a generator that encodes lazily."""
+        prev = None
+        for q in query_batches:
+            t = self.submit(q)
+            if prev is not None:
+                yield self.finish(prev, k)
+            prev = t
+        if prev is not None:
+            yield self.finish(prev, k)

@@ -4,7 +4,7 @@ torch is used for allocation, stream identity and host<->device copies only.  Ev
 CUDA (ROCm) tensors and raises otherwise: there is no CPU path in the product."""
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -12,10 +12,14 @@ from . import _lib
 
 
 def _need_gpu(*ts):
+    dev = None
     for t in ts:
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
             raise _lib.TsimError("text_similarity_amd ops run on MI355X only: expected a CUDA/ROCm tensor, "
                                  f"got {type(t).__name__} on {getattr(t, 'device', None)}")
+        if dev is not None and t.device != dev:
+            raise ValueError(f"operands on different devices: {dev} and {t.device}")
+        dev = t.device
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -26,7 +30,9 @@ _workspaces = {}
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    """Scratch for one search call, keyed by (device, current stream): calls on different streams never share it, and
+    calls on one stream are ordered by the stream."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
@@ -53,46 +59,73 @@ def l2norm_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
     ld = pad_dim(d)
     out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
     dt = _lib.TSIM_F32 if x.dtype == torch.float32 else _lib.TSIM_BF16
-    _lib.check(_lib.lib().tsim_l2norm_rows(x.data_ptr(), dt, rows, d, x.stride(0), out.data_ptr(), ld, eps,
-                                           _stream(x)), "l2norm_rows")
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().tsim_l2norm_rows(x.data_ptr(), dt, rows, d, x.stride(0), out.data_ptr(), ld, eps,
+                                               _stream(x)), "l2norm_rows")
     return out
 
 
-def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, idx_offset: int = 0
-                ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Top-k inner products of unit bf16 rows (outputs of l2norm_rows): scores [Q,k] f32, idx [Q,k] i64,
-    ordered by (score desc, index asc)."""
+def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, idx_offset: int = 0,
+                eq_f32: Optional[torch.Tensor] = None, ec_f32: Optional[torch.Tensor] = None,
+                return_status: bool = False):
+    """Top-k of every query row against every corpus row: scores [Q,k] f32, idx [Q,k] i64, ordered by (score desc,
+    index asc).  ``eq_unit`` / ``ec_unit`` are the unit bf16 rows from :func:`l2norm_rows` (what the MFMA kernel streams).
+    With ``eq_f32`` / ``ec_f32`` (the float32 embeddings the unit rows were made from) the returned scores are the
+    reference's ``F.cosine_similarity`` of the float32 rows (/root/reference/src/pipeline/search_pipeline.py:76-78) and the
+    order is exact for them; without, the inner product of the unit rows as stored.  ``return_status`` adds an int32 [Q]
+    tensor: 0 = first pass, 1 = widened, 2 = brute force (include/tsim.h).  1 <= k <= 64, d <= 768."""
     _need_gpu(eq_unit, ec_unit)
     if eq_unit.dtype != torch.bfloat16 or ec_unit.dtype != torch.bfloat16:
         raise ValueError("cosine_topk expects bf16 unit rows from l2norm_rows")
     ld = pad_dim(d)
     if eq_unit.shape[1] != ld or ec_unit.shape[1] != ld or not eq_unit.is_contiguous() or not ec_unit.is_contiguous():
         raise ValueError(f"cosine_topk: rows must be contiguous with stride pad_dim({d})={ld}")
+    if (eq_f32 is None) != (ec_f32 is None):
+        raise ValueError("cosine_topk: pass both float32 matrices or neither")
     Q, N = eq_unit.shape[0], ec_unit.shape[0]
-    scores = torch.empty((Q, k), dtype=torch.float32, device=eq_unit.device)
-    idx = torch.empty((Q, k), dtype=torch.int64, device=eq_unit.device)
+    dev = eq_unit.device
+    if ec_unit.device != dev:
+        raise ValueError(f"cosine_topk: operands on different devices ({dev} vs {ec_unit.device})")
+    qf = cf = 0
+    ldq = ldc = 0
+    if eq_f32 is not None:
+        _need_gpu(eq_f32, ec_f32)
+        for t, rows, name in ((eq_f32, Q, "eq_f32"), (ec_f32, N, "ec_f32")):
+            if t.dtype != torch.float32 or t.dim() != 2 or t.shape != (rows, d) or t.stride(1) != 1 or t.device != dev:
+                raise ValueError(f"cosine_topk: {name} must be float32 [{rows}, {d}] with unit inner stride on {dev}")
+        qf, cf, ldq, ldc = eq_f32.data_ptr(), ec_f32.data_ptr(), eq_f32.stride(0), ec_f32.stride(0)
+    scores = torch.empty((Q, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    status = torch.zeros((Q,), dtype=torch.int32, device=dev) if return_status else None
     if Q == 0:
-        return scores, idx
+        return (scores, idx, status) if return_status else (scores, idx)
     L = _lib.lib()
-    nbytes = L.tsim_cosine_topk_workspace_bytes(Q, N, k)
-    ws = _workspace(eq_unit.device, nbytes)
-    _lib.check(L.tsim_cosine_topk(eq_unit.data_ptr(), Q, ec_unit.data_ptr(), N, d, ld, k, scores.data_ptr(),
-                                  idx.data_ptr(), idx_offset, ws.data_ptr(), ws.numel(), _stream(eq_unit)),
-               "cosine_topk")
-    return scores, idx
+    with torch.cuda.device(dev):
+        nbytes = L.tsim_cosine_topk_workspace_bytes(Q, N, k)
+        if nbytes == 0:
+            raise ValueError(f"cosine_topk: unsupported shape Q={Q} N={N} k={k} (1 <= k <= 64)")
+        ws = _workspace(dev, nbytes)
+        _lib.check(L.tsim_cosine_topk_ex(eq_unit.data_ptr(), qf, ldq, Q, ec_unit.data_ptr(), cf, ldc, N, d, ld, k,
+                                         scores.data_ptr(), idx.data_ptr(), status.data_ptr() if return_status else 0,
+                                         idx_offset, ws.data_ptr(), ws.numel(), _stream(eq_unit)), "cosine_topk")
+    return (scores, idx, status) if return_status else (scores, idx)
 
 
-def topk_merge(scores: Sequence[torch.Tensor], idx: Sequence[torch.Tensor], k: int
-               ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge per-shard/per-chunk [Q,k_in] lists (global indices) into [Q,k]."""
-    s = torch.stack([t.contiguous() for t in scores]).contiguous()
-    i = torch.stack([t.contiguous() for t in idx]).contiguous()
+def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge per-shard/per-chunk lists (global indices) into [Q,k].  ``scores`` / ``idx`` are either sequences of [Q,k_in]
+    tensors or already stacked [nlists, Q, k_in] tensors (no copy then)."""
+    s = scores if isinstance(scores, torch.Tensor) else torch.stack([t.contiguous() for t in scores])
+    i = idx if isinstance(idx, torch.Tensor) else torch.stack([t.contiguous() for t in idx])
+    s, i = s.contiguous(), i.contiguous()
     _need_gpu(s, i)
+    if s.dtype != torch.float32 or i.dtype != torch.int64 or s.shape != i.shape or s.dim() != 3:
+        raise ValueError("topk_merge expects float32 scores and int64 indices of one shape [nlists, Q, k_in]")
     nl, Q, k_in = s.shape
     out_s = torch.empty((Q, k), dtype=torch.float32, device=s.device)
     out_i = torch.empty((Q, k), dtype=torch.int64, device=s.device)
-    _lib.check(_lib.lib().tsim_topk_merge(s.data_ptr(), i.data_ptr(), nl, Q, k_in, k, out_s.data_ptr(),
-                                          out_i.data_ptr(), _stream(s)), "topk_merge")
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.lib().tsim_topk_merge(s.data_ptr(), i.data_ptr(), nl, Q, k_in, k, out_s.data_ptr(),
+                                              out_i.data_ptr(), _stream(s)), "topk_merge")
     return out_s, out_i
 
 
@@ -103,8 +136,9 @@ def cos_sim_dense(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if a.shape[1] != b.shape[1]:
         raise ValueError("cos_sim: width mismatch")
     out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
-    _lib.check(_lib.lib().tsim_cos_sim(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1],
-                                       out.data_ptr(), _stream(a)), "cos_sim")
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().tsim_cos_sim(a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], a.shape[1],
+                                           out.data_ptr(), _stream(a)), "cos_sim")
     return out
 
 
@@ -118,8 +152,9 @@ def mean_pool(hidden: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     B, S, H = hidden.shape
     out = torch.empty((B, H), dtype=torch.float32, device=hidden.device)
     dt = _lib.TSIM_F32 if hidden.dtype == torch.float32 else _lib.TSIM_BF16
-    _lib.check(_lib.lib().tsim_mean_pool(hidden.data_ptr(), dt, m.data_ptr(), B, S, H, out.data_ptr(),
-                                         _stream(hidden)), "mean_pool")
+    with torch.cuda.device(hidden.device):
+        _lib.check(_lib.lib().tsim_mean_pool(hidden.data_ptr(), dt, m.data_ptr(), B, S, H, out.data_ptr(),
+                                             _stream(hidden)), "mean_pool")
     return out
 
 

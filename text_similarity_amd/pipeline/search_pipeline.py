@@ -60,11 +60,14 @@ class SentenceMiningPipeline(SearchPipeline):
         self.last_indices = None
 
     def search_tensors(self, query_embeddings: torch.Tensor, corpus=None, max_num_results: int = 10):
-        """Device-level search: returns (scores [Q,k] f32, indices [Q,k] i64) over the whole corpus."""
+        """Device-level search: returns (scores [Q,k] f32, indices [Q,k] i64) over the whole corpus.  Scores are the
+        reference's ``F.cosine_similarity`` of the float32 embeddings (search_pipeline.py:76-77) and the order is exact for
+        them: bf16 unit rows feed the MFMA kernel for candidate selection only.  1 <= max_num_results <= 64, width <= 768."""
         corpus = self.corpus if corpus is None else corpus
         n = len(corpus)
         d = query_embeddings.shape[1]
-        qn = ops.l2norm_rows(query_embeddings.to(self.params.device))
+        qf = query_embeddings.to(self.params.device, dtype=torch.float32).contiguous()
+        qn = ops.l2norm_rows(qf)
         k = min(max_num_results, len(query_embeddings)) if self.reference_k_clamp else max_num_results
         k = max(1, min(k, n))
         scores, idxs = [], []
@@ -72,8 +75,9 @@ class SentenceMiningPipeline(SearchPipeline):
             chunk = corpus[start:start + self.corpus_chunk_size]
             if isinstance(chunk, list):
                 chunk = self.model.encode_text(chunk)
-            cn = ops.l2norm_rows(chunk.to(self.params.device))
-            s, i = ops.cosine_topk(qn, cn, d, min(k, cn.shape[0]), idx_offset=start)
+            cf = chunk.to(self.params.device, dtype=torch.float32).contiguous()
+            cn = ops.l2norm_rows(cf)
+            s, i = ops.cosine_topk(qn, cn, d, min(k, cn.shape[0]), idx_offset=start, eq_f32=qf, ec_f32=cf)
             if s.shape[1] < k:   # short last chunk: pad so lists stack
                 pad = k - s.shape[1]
                 s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"), device=s.device)], 1)
@@ -115,7 +119,8 @@ class SemanticSearchPipeline(SearchPipeline):
     ``_search`` / ``__call__`` returning ``{query_idx: [texts best-first]}``, ``add_to_index``, ``remove_from_index``,
     ``num_indexed``.  Differences: results are exact; ``ef`` / ``ef_construction`` / ``M`` are accepted and unused (the
     reference's ``assert max_num_results < ef`` has no meaning here); ``add_to_index`` also appends the texts to
-    ``self.corpus`` — the reference only grows the index, so its new ids cannot be mapped back to text."""
+    ``self.corpus`` — the reference only grows the index, so its new ids cannot be mapped back to text.
+    ``max_num_results`` up to 64 (the reference's bound is ``ef`` = 50, search_pipeline.py:131); width <= 768."""
 
     def __init__(self, index_path, *args, **kwargs):
         super().__init__(*args, **kwargs)

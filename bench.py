@@ -231,6 +231,8 @@ def main():
         q256 = torch.randn((256, d), generator=g, device=dev)
         u256 = ops.l2norm_rows(q256)
         e0, e1 = ev(), ev()
+        e0.record(stream)      # hipEventCreate happens at the first record
+        e1.record(stream)
         ts = []
         for _ in range(6):
             L.tsim_time_next_topk(e0.cuda_event, e1.cuda_event)

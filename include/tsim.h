@@ -12,8 +12,10 @@
  *     work on it, they never synchronise and never allocate device memory (except tsim_encoder_create);
  *   - return value 0 = ok, otherwise a TSIM_E* code; tsim_last_error() gives the message for the calling
  *     thread;
- *   - "bf16 rows" are row-major uint16 bfloat16 with a row stride of `ld` elements, ld a multiple of 8
- *     and every row 16-byte aligned; tsim_pad_dim(d) is the stride the engine itself produces.
+ *   - "unit rows" are row-major IEEE half (float16) L2-normalised rows with a row stride of `ld` elements, ld a multiple
+ *     of 8 and every row 16-byte aligned; tsim_pad_dim(d) is the stride the engine itself produces.  Half, not bf16:
+ *     the elements of a unit row are <= 1, the f16 MFMA runs at the bf16 rate, and 11 significand bits keep the MFMA
+ *     selection scores within ~1e-4 of the exact cosine (bf16: ~1e-3), which keeps the exactness guard quiet.
  */
 #ifndef TSIM_H
 #define TSIM_H
@@ -40,23 +42,23 @@ extern "C" {
 int tsim_version(void);
 const char *tsim_last_error(void);
 
-/* Row stride (elements) of the engine's internal bf16 embedding matrices for an embedding width d:
+/* Row stride (elements) of the engine's internal unit-row matrices for an embedding width d:
  * the smallest supported kernel width >= d (128, 256, 384, 512 or 768); 0 if d > 768. */
 int tsim_pad_dim(int d);
 
 /* ---------------------------------------------------------------------------------------------
  * A7  F.cosine_similarity operand preparation   /root/reference/src/pipeline/search_pipeline.py:77
- * out[r, :d] = bf16( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0, evaluated canonically: float64 sum of
- * squares in a fixed order, float64 reciprocal, one rounding float64 -> bf16 (oracle/search_ref.unit_rows is bit-identical).
+ * out[r, :d] = half( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0, evaluated canonically: float64 sum of
+ * squares in a fixed order, float64 reciprocal, one rounding float64 -> half (oracle/search_ref.unit_rows is bit-identical).
  * torch divides each operand by max(norm, eps) with eps = 1e-8; a zero row stays zero, so its score
  * against anything is 0.  x_dtype is TSIM_F32 or TSIM_BF16, ld_in its row stride in elements. */
 int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in,
-                     void *out_bf16, int ld_out, float eps, void *stream);
+                     void *out_f16, int ld_out, float eps, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A6/A7/A9  the per-query loop `expand_as -> F.cosine_similarity -> torch.topk`
  *           /root/reference/src/pipeline/search_pipeline.py:73-78, fused.
- * eq_unit [Q, ld] and ec_unit [N, ld] are L2-normalised bf16 rows (tsim_l2norm_rows).  MFMA inner products of those rows
+ * eq_unit [Q, ld] and ec_unit [N, ld] are L2-normalised half rows (tsim_l2norm_rows).  MFMA inner products of those rows
  * (scores live in registers, survivors go through per-lane queues in LDS; the N x Q matrix is never written) SELECT
  * candidates; every score that is returned, and the final order, comes from an exact re-score:
  *   - eq_f32 / ec_f32 given (float32 embeddings, row strides ldq_f32 / ldc_f32 elements): the reference's value
@@ -164,11 +166,11 @@ void tsim_encoder_destroy(tsim_encoder *enc);
  * cu_seqlens[b+1]; tok_ids/tok_pos int32 [T] (tok_pos = position-embedding row, tok_col = column of the
  * token in the padded batch, used for MPNet's relative bias; pass tok_col = NULL to use tok_pos).
  * Outputs (either may be NULL): pooled_f32 [B, hidden] = masked mean-pool (A4), un-normalised like the
- * reference's encode_text; unit_bf16 [B, ld_unit] = L2-normalised bf16 rows ready for tsim_cosine_topk;
+ * reference's encode_text; unit_f16 [B, ld_unit] = L2-normalised half rows ready for tsim_cosine_topk;
  * last_hidden_bf16 [T, hidden] for tests. */
 int tsim_encoder_forward(tsim_encoder *enc, const int32_t *tok_ids, const int32_t *tok_pos,
                          const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
-                         int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit,
+                         int32_t max_len, float *pooled_f32, void *unit_f16, int ld_unit,
                          void *last_hidden_bf16, void *stream);
 
 #ifdef __cplusplus

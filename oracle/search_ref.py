@@ -14,7 +14,7 @@ arithmetic; its published semantics are restated here in numpy.  Pinned against 
 the build container by the reference's own ``cos_sim`` and by torch ``cosine_similarity``/``topk``
 (tools/make_golden.py -> tests/golden/search_*.npz); see tests/test_oracle_golden.py.
 
-Exact scores.  The GPU path scores bf16 unit rows with MFMA (fp32 accumulate, hardware summation order) only to
+Exact scores.  The GPU path scores half-precision unit rows with MFMA (fp32 accumulate, hardware summation order) only to
 *select candidates*; every returned score and the final order come from an exact re-score in float64 in one fixed
 ("lane") order, rounded once to float32, so results are reproducible bit for bit:
 ``exact_cosine`` — the reference's F.cosine_similarity of the float32 embeddings (what ``cosine_topk_f32`` ranks), and
@@ -72,9 +72,11 @@ def l2_normalize(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
 
 
 def unit_rows(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
-    """The canonical search operand: L2-normalised rows rounded once to bf16 (bf16-exact float32) — what
-    tsim_l2norm_rows and the encoder's fused pooling epilogue store."""
-    return f64_to_bf16(l2_normalize_f64(x, eps))
+    """The canonical search operand: L2-normalised rows rounded ONCE to IEEE half (returned as half-exact float32) — what
+    tsim_l2norm_rows and the encoder's fused pooling epilogue store (text_similarity_amd/csrc/common.h f64_to_f16).
+    numpy's float64 -> float16 cast is a single correct rounding (nearest even), subnormal halves included."""
+    with np.errstate(over="ignore"):
+        return l2_normalize_f64(x, eps).astype(np.float16).astype(np.float32)
 
 
 def cosine_similarity_rows(x: np.ndarray, y: np.ndarray, eps: float = 1e-8) -> np.ndarray:
@@ -170,7 +172,7 @@ def cosine_topk_f32(q: np.ndarray, c: np.ndarray, k: int, idx_offset: int = 0, b
 
 def canonical_scores(eq: np.ndarray, ec: np.ndarray, qblock: int = 16, nblock: int = 8192) -> np.ndarray:
     """[Q,N] float32: inner product of the stored unit rows, float64 accumulation in the canonical lane order
-    (_lane_sum), one final rounding to float32.  Inputs are the (bf16-exact) normalised rows."""
+    (_lane_sum), one final rounding to float32.  Inputs are the (half-exact) normalised rows."""
     eq = np.asarray(eq, dtype=np.float32)
     ec = np.asarray(ec, dtype=np.float32)
     out = np.empty((eq.shape[0], ec.shape[0]), dtype=np.float32)

@@ -12,12 +12,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _unit_dev(x_f32_unit_bf16exact: np.ndarray, d: int):
-    """upload bf16-exact unit rows as the padded bf16 matrix the kernels consume"""
+def _unit_dev(x_f32: np.ndarray, d: int):
+    """upload rows as the padded float16 matrix the kernels consume (callers pass half-exact unit rows; anything else is
+    rounded to half here and by _h below, so GPU and oracle still see identical operands)"""
     ld = ops.pad_dim(d)
-    t = torch.zeros((x_f32_unit_bf16exact.shape[0], ld), dtype=torch.bfloat16)
-    t[:, :d] = torch.from_numpy(x_f32_unit_bf16exact).to(torch.bfloat16)
+    t = torch.zeros((x_f32.shape[0], ld), dtype=torch.float16)
+    t[:, :d] = torch.from_numpy(np.ascontiguousarray(x_f32, dtype=np.float32)).to(torch.float16)
     return t.to(DEV)
+
+
+def _h(x: np.ndarray) -> np.ndarray:
+    """the values _unit_dev stores: float32 -> half (nearest even) -> float32"""
+    return np.ascontiguousarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
 
 
 def _check_exact(q, c, k, idx_offset=0, oracle_queries=None):
@@ -25,6 +31,7 @@ def _check_exact(q, c, k, idx_offset=0, oracle_queries=None):
     (``oracle_queries``); every query still gets the checks that need no full oracle: returned scores are the canonical
     scores of the returned (query, row) pairs, lists are ordered by (score desc, index asc), indices are distinct."""
     d = q.shape[1]
+    q, c = _h(q), _h(c)
     s, i = ops.cosine_topk(_unit_dev(q, d), _unit_dev(c, d), d, k, idx_offset)
     torch.cuda.synchronize()
     s, i = s.cpu().numpy(), i.cpu().numpy()
@@ -182,7 +189,7 @@ def test_l2norm_rows_matches_oracle_bit_exact():
     ref = search_ref.unit_rows(x)
     np.testing.assert_array_equal(got, ref)
     assert (got[7] == 0).all() and (u[:, 384:] == 0).all()
-    xb = torch.from_numpy(x).to(torch.bfloat16).to(DEV)
+    xb = torch.from_numpy(x).to(torch.bfloat16).to(DEV)      # bf16 INPUT rows (encoder hidden states) are accepted too
     ub = ops.l2norm_rows(xb)
     refb = search_ref.unit_rows(xb.float().cpu().numpy())
     np.testing.assert_array_equal(ub[:, :384].float().cpu().numpy(), refb)

@@ -55,9 +55,9 @@ def _worker(rank, world, port, n_total, k, mode, out_dir):
         d = 384
         corpus, queries = _data(n_total, world)
         lo, hi = shard_bounds(n_total, world, rank)
-        c_unit = torch.from_numpy(search_ref.unit_rows(corpus[lo:hi])).to(torch.bfloat16)
+        c_unit = torch.from_numpy(search_ref.unit_rows(corpus[lo:hi])).to(torch.float16)
         if mode == "unit":
-            q_local = torch.from_numpy(search_ref.unit_rows(queries[rank * 8:(rank + 1) * 8])).to(torch.bfloat16)
+            q_local = torch.from_numpy(search_ref.unit_rows(queries[rank * 8:(rank + 1) * 8])).to(torch.float16)
             eng = ShardedCorpusSearch(c_unit, d, lo, local_search=_oracle_local, merge=_oracle_merge)
         else:
             # un-normalised float32 embeddings (scaled rows: the cosine must not care)

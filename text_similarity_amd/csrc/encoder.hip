@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
 template <int VPL>
 __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restrict__ x,
                                                           const int32_t *__restrict__ cu, int B, int H,
-                                                          float *__restrict__ pooled, bf16_t *__restrict__ unit,
+                                                          float *__restrict__ pooled, unit_t *__restrict__ unit,
                                                           int ld_unit) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1244,7 +1244,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     }
     if (pooled_f32 || unit_bf16) {
         const unsigned g = (unsigned)((B + 3) / 4);
-#define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (bf16_t *)unit_bf16, ld_unit)
+#define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (unit_t *)unit_bf16, ld_unit)
         if (H == 64) POOL(1); else if (H == 384) POOL(6); else POOL(12);
 #undef POOL
         TSIM_HIP_CHECK(hipGetLastError());

@@ -19,7 +19,7 @@ namespace tsim {
 // VGPRs = 96 VGPRs at D = 384), so the only operand that moves in the main loop is the corpus.  Corpus
 // tiles of 32 rows stream HBM -> LDS with LDS-DMA (global_load_lds_dwordx4, a 3-stage ring, counted vmcnt,
 // one raw s_barrier per tile) and are shared by all waves of the workgroup.  Per tile and wave: D/16
-// v_mfma_f32_32x32x16_bf16 with A = corpus tile (ds_read_b128 from an XOR-swizzled row-major image), the
+// v_mfma_f32_32x32x16_f16 with A = corpus tile (ds_read_b128 from an XOR-swizzled row-major image), the
 // 32x32 score tile stays in 16 accumulator VGPRs: lane (r, h) holds query r against corpus rows
 // {(reg&3) + 8*(reg>>2) + 4*h}.  Because the query sits on the lane, top-k selection needs no cross-lane
 // traffic: one threshold VGPR (the lane's current KL-th best), a max3 tree over the 16 accumulators and a
@@ -132,7 +132,7 @@ struct K1Collect {
 
 template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
-    const bf16_t *__restrict__ eq, int Q, const bf16_t *__restrict__ ec, int64_t N, int rows_per_chunk,
+    const unit_t *__restrict__ eq, int Q, const unit_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
     int *__restrict__ part_i, K1Collect coll) {
 #ifdef TSIM_PP_STAMPS
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const bool wave_on = q0 < Q;  // wave-uniform: waves past the last query only help staging
 
     // ---- resident query fragments: B[k = 8h + j][col r] of k-step s = eq[q0 + 32u + r][16 s + 8 h + j]
-    bf16x8 bq[QW][KSTEPS];
+    f16x8 bq[QW][KSTEPS];
     float thr[QW];
     int *gt[QW];   // this lane's query's shared threshold word
 #pragma unroll
@@ -188,9 +188,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         const int qrow = (q0 + 32 * u + r < Q) ? (q0 + 32 * u + r) : (Q - 1);
         int qsrc = qrow;
         if constexpr (COLLECT) qsrc = wave_on ? coll.qmap[qrow] : 0;
-        const bf16_t *qp = eq + (int64_t)qsrc * D + 8 * h;
+        const unit_t *qp = eq + (int64_t)qsrc * D + 8 * h;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+        for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const f16x8 *>(qp + 16 * s);
         if constexpr (MAXONLY) {   // pre-pass: no thresholds (gthr is null)
             gt[u] = nullptr;
             thr[u] = -INFINITY;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
                     if constexpr (sidx + PF < KSTEPS) rd(std::integral_constant<int, sidx + PF>{});
                     constexpr int younger = sidx + PF < KSTEPS ? PF : KSTEPS - 1 - sidx;
                     k1_lgkm_wait<younger>(fr[sidx % (PF + 1)]);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[sidx % (PF + 1)]), bq[0][sidx],
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[sidx % (PF + 1)]), bq[0][sidx],
                                                                      acc[0], 0, 0, 0);
                 };
                 k1_static_for(std::make_integer_sequence<int, PF>{}, rd);
@@ -399,29 +399,29 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
                 // s, so an LDS read has PF MFMAs (PF*32 pipe cycles) to land; sched_group_barrier pins the interleave and
                 // the compiler's counted lgkmcnt waits follow from it.
                 constexpr int PF = 4;
-                bf16x8 fr[PF + 1];
+                f16x8 fr[PF + 1];
 #pragma unroll
                 for (int i = 0; i < PF; ++i)
-                    fr[i] = *reinterpret_cast<const bf16x8 *>(abase + aoff[i & 7] + (i >> 3) * 256);
+                    fr[i] = *reinterpret_cast<const f16x8 *>(abase + aoff[i & 7] + (i >> 3) * 256);
                 __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) {
                     if (s + PF < KSTEPS) {
                         const int n = s + PF;
-                        fr[n % (PF + 1)] = *reinterpret_cast<const bf16x8 *>(abase + aoff[n & 7] + (n >> 3) * 256);
+                        fr[n % (PF + 1)] = *reinterpret_cast<const f16x8 *>(abase + aoff[n & 7] + (n >> 3) * 256);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s % (PF + 1)], bq[0][s], acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[s % (PF + 1)], bq[0][s], acc[0], 0, 0, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 }
             }
         } else {
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
+                const f16x8 a = *reinterpret_cast<const f16x8 *>(abase + aoff[s & 7] + (s >> 3) * 256);
 #pragma unroll
                 for (int u = 0; u < QW; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[u][s], acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[u][s], acc[u], 0, 0, 0);
             }
         }
         filter(std::integral_constant<int, 0>{}, acc[0], t);
@@ -577,7 +577,7 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
 }
 
 template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false>
-static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -600,7 +600,7 @@ static int launch_k1(const TopkPlan &p, const bf16_t *eq, int64_t Q, const bf16_
 }
 
 template <int KL, bool MAXONLY = false, bool COLLECT = false>
-static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+static int launch_k1_kl(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                         float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     switch (D) {
         case 128: return launch_k1<128, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
@@ -619,14 +619,14 @@ static int launch_k1_kl(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, c
 }
 
 // threshold pre-pass over the first rows of the corpus (block maxima only); defined in k1_kl16.hip
-int k1_launch_blockmax(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+int k1_launch_blockmax(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                        float *bmax, hipStream_t st);
-int k1_launch_kl16(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+int k1_launch_kl16(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                    float *part_s, int *part_i, int *gthr, hipStream_t st);
-int k1_launch_kl32(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N,
+int k1_launch_kl32(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                    float *part_s, int *part_i, int *gthr, hipStream_t st);
 // widening pass (COLLECT mode) over at most Q slots; defined in k1_collect.hip
-int k1_launch_collect(const TopkPlan &p, int D, const bf16_t *eq, int64_t Q, const bf16_t *ec, int64_t N, int *gthr_slots,
+int k1_launch_collect(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N, int *gthr_slots,
                       K1Collect coll, hipStream_t st);
 
 }  // namespace tsim

@@ -23,10 +23,12 @@ template <>
 __device__ __forceinline__ float load_as_f32<float>(const float *p) { return *p; }
 template <>
 __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <>
+__device__ __forceinline__ float load_as_f32<unit_t>(const unit_t *p) { return (float)*p; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ x, int64_t rows, int d,
-                                                          int64_t ld_in, bf16_t *__restrict__ out, int ld_out,
+                                                          int64_t ld_in, unit_t *__restrict__ out, int ld_out,
                                                           float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -38,8 +40,8 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ 
         ss = fma(v, v, ss);
     }
     const double inv = canonical_inv_norm(ss, eps);
-    bf16_t *o = out + row * (int64_t)ld_out;
-    for (int j = lane; j < ld_out; j += 64) o[j] = j < d ? canonical_unit_elem(load_as_f32<T>(xr + j), inv) : (bf16_t)0;
+    unit_t *o = out + row * (int64_t)ld_out;
+    for (int j = lane; j < ld_out; j += 64) o[j] = j < d ? canonical_unit_elem(load_as_f32<T>(xr + j), inv) : (unit_t)0;
 }
 
 // =====================================================================================================
@@ -675,19 +677,19 @@ extern "C" int tsim_pad_dim(int d) {
     return 0;
 }
 
-extern "C" int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in, void *out_bf16,
+extern "C" int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in, void *out_f16,
                                 int ld_out, float eps, void *stream) {
-    TSIM_REQUIRE(x && out_bf16, "l2norm_rows: null pointer");
+    TSIM_REQUIRE(x && out_f16, "l2norm_rows: null pointer");
     TSIM_REQUIRE(rows >= 0 && d > 0 && ld_in >= d && ld_out >= d, "l2norm_rows: bad shape rows=%lld d=%d ld_in=%lld ld_out=%d",
                  (long long)rows, d, (long long)ld_in, ld_out);
     if (rows == 0) return TSIM_OK;
     const unsigned grid = (unsigned)((rows + 3) / 4);
     if (x_dtype == TSIM_F32)
         hipLaunchKernelGGL(l2norm_rows_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const float *)x, rows, d, ld_in, (bf16_t *)out_bf16, ld_out, eps);
+                           (const float *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps);
     else if (x_dtype == TSIM_BF16)
         hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const bf16_t *)x, rows, d, ld_in, (bf16_t *)out_bf16, ld_out, eps);
+                           (const bf16_t *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps);
     else
         return fail(TSIM_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
     TSIM_HIP_CHECK(hipGetLastError());
@@ -744,7 +746,7 @@ static void plan_workspace(int64_t Q, int64_t N, int k, SearchWs *w) {
 // plan of the widening pass: enough chunks that ONE flagged query block still spreads over the chip
 static void plan_collect(int64_t Q, int64_t N, int D, TopkPlan *p) {
     plan_topk(Q, N, D, 1, p);
-    int64_t nch = 128, max_ch = (N + 255) / 256;
+    int64_t nch = 256, max_ch = (N + 255) / 256;
     if (nch > max_ch) nch = max_ch;
     if (nch < 8) {   // the kernel's block map wants 1, 2, 4 or >= 8 chunks
         int p2 = 1;
@@ -790,7 +792,7 @@ static float guard_c1() {
 }
 
 template <typename T, bool COS>
-static int search_tail(const SearchWs &w, char *ws, int64_t Q, int64_t N, const bf16_t *eq, const bf16_t *ec, int ld,
+static int search_tail(const SearchWs &w, char *ws, int64_t Q, int64_t N, const unit_t *eq, const unit_t *ec, int ld,
                        const T *xq, int64_t ldq, const T *xc, int64_t ldc, int d, int k, float *out_s, int64_t *out_i,
                        int64_t idx_offset, const GuardArgs &g, bool run_collect, hipStream_t st) {
     // widening pass + its finalisation (workgroups leave at once when nothing was flagged) ...
@@ -864,7 +866,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
     int *gthr = reinterpret_cast<int *>(ws + w.gthr);   // per-query shared threshold words, re-initialised every call
     float *bmax = reinterpret_cast<float *>(ws + w.bmax);
     hipStream_t st = as_stream(stream);
-    const bf16_t *uq = (const bf16_t *)eq, *uc = (const bf16_t *)ec;
+    const unit_t *uq = (const unit_t *)eq, *uc = (const unit_t *)ec;
 
     GuardArgs g;
     g.c1 = guard_c1();
@@ -911,9 +913,9 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
             else launch_finalize<32, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, out_scores,
                                                   out_idx, idx_offset, g, st);
         } else {
-            if (p.KL == 16) launch_finalize<16, bf16_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores,
+            if (p.KL == 16) launch_finalize<16, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores,
                                                                out_idx, idx_offset, g, st);
-            else launch_finalize<32, bf16_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores, out_idx,
+            else launch_finalize<32, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores, out_idx,
                                                     idx_offset, g, st);
         }
         TSIM_HIP_CHECK(hipGetLastError());
@@ -936,7 +938,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
     if (cosf)
         return search_tail<float, true>(w, ws, Q, N, uq, uc, ld, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, out_scores, out_idx,
                                         idx_offset, g, run_collect, st);
-    return search_tail<bf16_t, false>(w, ws, Q, N, uq, uc, ld, uq, ld, uc, ld, ld, k, out_scores, out_idx, idx_offset, g,
+    return search_tail<unit_t, false>(w, ws, Q, N, uq, uc, ld, uq, ld, uc, ld, ld, k, out_scores, out_idx, idx_offset, g,
                                       run_collect, st);
 }
 

@@ -2,7 +2,7 @@
 over xGMI on ROCm).  The reference has no multi-device code at all; this is the scale-out of
 ``SentenceMiningPipeline._search`` (/root/reference/src/pipeline/search_pipeline.py:60-89) for BASELINE.json config 4.
 
-Partitioning: rank r owns corpus rows [offset_r, offset_r + n_r) — the float32 embeddings and their unit bf16 rows,
+Partitioning: rank r owns corpus rows [offset_r, offset_r + n_r) — the float32 embeddings and their unit float16 rows,
 resident in its HBM; the corpus never moves.  Per query batch there are exactly two exchanges, both tiny and
 latency-bound:
   1. all-gather of the query embeddings   [Q_local, d] float32 per rank  -> [Q, d] everywhere (unit rows are made locally)
@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset):
     from .. import ops
-    if c_f32 is None:                       # unit rows only: q_f32 holds unit bf16 rows
+    if c_f32 is None:                       # unit rows only: q_f32 holds unit float16 rows
         return ops.cosine_topk(q_f32, c_unit, d, k, idx_offset=offset)
     q_unit = ops.l2norm_rows(q_f32)
     return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32)
@@ -59,7 +59,7 @@ class ShardedCorpusSearch:
                  local_search: Callable = _hip_local_search, merge: Callable = _hip_merge,
                  corpus_f32_local: Optional[torch.Tensor] = None):
         """``corpus_f32_local`` [n_r, d] float32: the embeddings (scores are then the reference's cosines of float32 rows and
-        queries are passed as float32 embeddings); without it queries are unit bf16 rows and scores their inner products."""
+        queries are passed as float32 embeddings); without it queries are unit float16 rows and scores their inner products."""
         self.corpus = corpus_unit_local
         self.corpus_f32 = corpus_f32_local
         self.d = int(d)
@@ -83,10 +83,10 @@ class ShardedCorpusSearch:
 
     def gather_queries(self, q_local: torch.Tensor) -> torch.Tensor:
         """all-gather of equally sized query slices: [Q_local, w] -> [world*Q_local, w] (rank-major); float32 embeddings or
-        unit bf16 rows."""
+        unit float16 rows."""
         if self.world == 1:
             return q_local
-        # rows travel as raw bytes so that the gloo test backend (no bf16 support) runs the same code
+        # rows travel as raw bytes so that the gloo test backend (no half/bf16 support) runs the same code
         src = q_local.contiguous().view(torch.uint8)
         out = torch.empty((self.world * src.shape[0], src.shape[1]), dtype=torch.uint8, device=src.device)
         self._all_gather(out, src)

@@ -4,12 +4,12 @@
 ``set_ef``.  Every query is a brute-force pass of the fused MFMA cosine + top-k kernel, so results are exact (hnswlib's are
 approximate) and ordered by (score desc, label-row asc).
 
-Layout: float32 rows ``[capacity, d]`` as given (the reference's scores are cosines of these) + their unit bf16 rows
+Layout: float32 rows ``[capacity, d]`` as given (the reference's scores are cosines of these) + their unit float16 rows
 ``[capacity, pad_dim(d)]`` (what the MFMA kernel streams to select candidates) + int64 labels + a tombstone mask.
 Deleting marks a tombstone; the matrices are compacted (one device gather) before the next query, so deleted rows cost
 nothing afterwards and labels stay stable.  On disk (``index.bin``, a numpy ``.npz`` written without pickling): the
-float32 live rows, their labels, ``d`` (unit rows are recomputed on load; files written by the first version of this
-index hold bf16 unit rows only and are searched by their inner product).  k <= 64, d <= 768.
+float32 live rows, their labels, ``d`` (unit rows are recomputed on load; a file written by the first version of this
+index holds bf16 unit rows only, which then ARE the float32 rows).  k <= 64, d <= 768.
 """
 from __future__ import annotations
 
@@ -28,8 +28,8 @@ class GpuFlatIndex:
             raise ValueError("GpuFlatIndex implements the cosine space only")
         self.dim = int(dim)
         self.device = torch.device(device) if device is not None else torch.device("cuda")
-        self._rows: Optional[torch.Tensor] = None      # [capacity, ld] bf16 unit rows
-        self._f32: Optional[torch.Tensor] = None       # [capacity, d] float32 rows as given (None: unit rows only)
+        self._rows: Optional[torch.Tensor] = None      # [capacity, ld] float16 unit rows
+        self._f32: Optional[torch.Tensor] = None       # [capacity, d] float32 rows as given
         self._labels: Optional[torch.Tensor] = None    # [capacity] int64
         self._dead: Optional[torch.Tensor] = None      # [capacity] bool
         self._n = 0
@@ -68,8 +68,6 @@ class GpuFlatIndex:
             raise ValueError("ids and data disagree in length")
         xf = x.to(self.device, dtype=torch.float32).contiguous()
         unit = ops.l2norm_rows(xf)
-        if self._f32 is None and self._n > 0:
-            raise RuntimeError("this index was loaded from a unit-row-only file: rebuild it to add items")
         self._reserve(self._n + n)
         self._rows[self._n:self._n + n] = unit
         self._f32[self._n:self._n + n] = xf
@@ -105,10 +103,7 @@ class GpuFlatIndex:
             Q = q.shape[0]
             return (torch.full((Q, k), -1, dtype=torch.int64, device=self.device),
                     torch.full((Q, k), float("-inf"), device=self.device))
-        if self._f32 is not None:
-            s, i = ops.cosine_topk(qn, self._rows[:self._n], self.dim, k, eq_f32=qf, ec_f32=self._f32[:self._n])
-        else:
-            s, i = ops.cosine_topk(qn, self._rows[:self._n], self.dim, k)
+        s, i = ops.cosine_topk(qn, self._rows[:self._n], self.dim, k, eq_f32=qf, ec_f32=self._f32[:self._n])
         lab = torch.where(i >= 0, self._labels[i.clamp(min=0)], torch.full_like(i, -1))
         return lab, s
 
@@ -118,13 +113,9 @@ class GpuFlatIndex:
         if os.path.isdir(path):
             path = os.path.join(path, "index.bin")
         labels = self._labels[:self._n].cpu().numpy() if self._n else np.zeros((0,), np.int64)
+        rows = self._f32[:self._n].cpu().numpy() if self._n else np.zeros((0, self.dim), np.float32)
         with open(path, "wb") as f:
-            if self._f32 is not None or self._n == 0:
-                rows = self._f32[:self._n].cpu().numpy() if self._n else np.zeros((0, self.dim), np.float32)
-                np.savez(f, rows_f32=rows, labels=labels, dim=np.int64(self.dim))
-            else:
-                rows = self._rows[:self._n, :self.dim].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
-                np.savez(f, rows_bf16=rows, labels=labels, dim=np.int64(self.dim))
+            np.savez(f, rows_f32=rows, labels=labels, dim=np.int64(self.dim))
 
     def load_index(self, path: str, max_elements: int = 0):
         if os.path.isdir(path):
@@ -136,27 +127,20 @@ class GpuFlatIndex:
         self._n = self._n_dead = 0
         if "rows_f32" in z.files:
             rows = z["rows_f32"]
-            n = rows.shape[0]
-            self._reserve(max(n, int(max_elements)))
-            if n:
-                xf = torch.from_numpy(rows).to(self.device)
-                self._f32[:n] = xf
-                self._rows[:n] = ops.l2norm_rows(xf)
-        else:   # first-version file: unit rows only
-            rows = z["rows_bf16"]
-            n = rows.shape[0]
-            self._reserve(max(n, int(max_elements)), with_f32=False)
-            if n:
-                ld = ops.pad_dim(self.dim)
-                t = torch.zeros((n, ld), dtype=torch.bfloat16, device=self.device)
-                t[:, :self.dim] = torch.from_numpy(rows.view(np.int16)).to(self.device).view(torch.bfloat16)
-                self._rows[:n] = t
+        else:   # first-version file: bf16 bit patterns of unit rows
+            rows = (z["rows_bf16"].astype(np.uint32) << np.uint32(16)).view(np.float32)
+        n = rows.shape[0]
+        self._reserve(max(n, int(max_elements)))
+        if n:
+            xf = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
+            self._f32[:n] = xf
+            self._rows[:n] = ops.l2norm_rows(xf)
         if n:
             self._labels[:n] = torch.from_numpy(labels).to(self.device)
             self._n = n
 
     # ------------------------------------------------------------------ internals
-    def _reserve(self, n: int, with_f32: bool = True):
+    def _reserve(self, n: int):
         if self.dim == 0:
             return
         cap = 0 if self._rows is None else self._rows.shape[0]
@@ -164,12 +148,11 @@ class GpuFlatIndex:
             return
         new_cap = max(n, 2 * cap, 1024)
         ld = ops.pad_dim(self.dim)
-        rows = torch.zeros((new_cap, ld), dtype=torch.bfloat16, device=self.device)
-        if with_f32 and (self._f32 is not None or self._n == 0):
-            f32 = torch.zeros((new_cap, self.dim), dtype=torch.float32, device=self.device)
-            if self._f32 is not None and self._n:
-                f32[:self._n] = self._f32[:self._n]
-            self._f32 = f32
+        rows = torch.zeros((new_cap, ld), dtype=ops.UNIT_DTYPE, device=self.device)
+        f32 = torch.zeros((new_cap, self.dim), dtype=torch.float32, device=self.device)
+        if self._f32 is not None and self._n:
+            f32[:self._n] = self._f32[:self._n]
+        self._f32 = f32
         labels = torch.full((new_cap,), -1, dtype=torch.int64, device=self.device)
         dead = torch.zeros((new_cap,), dtype=torch.bool, device=self.device)
         if self._rows is not None and self._n:
@@ -184,8 +167,7 @@ class GpuFlatIndex:
         keep = (~self._dead[:self._n]).nonzero(as_tuple=False).squeeze(1)
         m = keep.numel()
         self._rows[:m] = self._rows[keep]
-        if self._f32 is not None:
-            self._f32[:m] = self._f32[keep]
+        self._f32[:m] = self._f32[keep]
         self._labels[:m] = self._labels[keep]
         self._dead[:self._n] = False
         self._n, self._n_dead = m, 0

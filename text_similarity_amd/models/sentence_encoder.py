@@ -50,7 +50,7 @@ class _EncodeMixin:
         return self.projection(pooler(hidden, features))
 
     def encode_packed(self, flat_ids: torch.Tensor, cu: torch.Tensor, unit: bool = False):
-        """Device-resident pre-tokenised input (the benchmark path): pooled f32 [B,H] (+ unit bf16 rows)."""
+        """Device-resident pre-tokenised input (the benchmark path): pooled f32 [B,H] (+ unit float16 rows)."""
         enc: NativeEncoder = self.context_embedder
         B = cu.numel() - 1
         outs, units = [], []

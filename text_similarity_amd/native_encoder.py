@@ -156,7 +156,7 @@ class NativeEncoder:
                        cols: Optional[torch.Tensor] = None, max_len: Optional[int] = None, pooled: bool = True,
                        unit: bool = False, hidden: bool = False):
         """flat_ids int32 [T], cu int32 [B+1] on the GPU.  Returns dict with 'pooled' f32 [B,H],
-        'unit' bf16 [B,pad_dim(H)], 'hidden' bf16 [T,H] as requested."""
+        'unit' float16 [B,pad_dim(H)] (L2-normalised rows for the search kernel), 'hidden' bf16 [T,H] as requested."""
         ops._need_gpu(flat_ids, cu)
         flat_ids = flat_ids.to(torch.int32).contiguous()
         cu = cu.to(torch.int32).contiguous()
@@ -172,7 +172,7 @@ class NativeEncoder:
         out = {}
         dev = flat_ids.device
         p = torch.empty((B, H), dtype=torch.float32, device=dev) if pooled else None
-        u = torch.empty((B, ops.pad_dim(H)), dtype=torch.bfloat16, device=dev) if unit else None
+        u = torch.empty((B, ops.pad_dim(H)), dtype=ops.UNIT_DTYPE, device=dev) if unit else None
         hd = torch.empty((T, H), dtype=torch.bfloat16, device=dev) if hidden else None
         _lib.check(_lib.lib().tsim_encoder_forward(
             self._h, flat_ids.data_ptr(), pos.data_ptr(), cols.data_ptr() if cols is not None else None,

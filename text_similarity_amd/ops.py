@@ -26,6 +26,8 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+UNIT_DTYPE = torch.float16      # storage type of the unit rows the MFMA search kernel streams (csrc/common.h unit_t)
+
 _workspaces = {}
 
 
@@ -48,7 +50,7 @@ def pad_dim(d: int) -> int:
 
 
 def l2norm_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
-    """[rows, d] float32/bf16 -> unit rows in bf16, zero-padded to [rows, pad_dim(d)] (A7 operand prep)."""
+    """[rows, d] float32/bf16 -> unit rows in float16 (IEEE half), zero-padded to [rows, pad_dim(d)] (A7 operand prep)."""
     _need_gpu(x)
     if x.dim() != 2:
         raise ValueError("l2norm_rows expects a 2-D tensor")
@@ -57,7 +59,7 @@ def l2norm_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
     x = x.contiguous()
     rows, d = x.shape
     ld = pad_dim(d)
-    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((rows, ld), dtype=UNIT_DTYPE, device=x.device)
     dt = _lib.TSIM_F32 if x.dtype == torch.float32 else _lib.TSIM_BF16
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().tsim_l2norm_rows(x.data_ptr(), dt, rows, d, x.stride(0), out.data_ptr(), ld, eps,
@@ -69,14 +71,14 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
                 eq_f32: Optional[torch.Tensor] = None, ec_f32: Optional[torch.Tensor] = None,
                 return_status: bool = False):
     """Top-k of every query row against every corpus row: scores [Q,k] f32, idx [Q,k] i64, ordered by (score desc,
-    index asc).  ``eq_unit`` / ``ec_unit`` are the unit bf16 rows from :func:`l2norm_rows` (what the MFMA kernel streams).
+    index asc).  ``eq_unit`` / ``ec_unit`` are the unit float16 rows from :func:`l2norm_rows` (what the MFMA kernel streams).
     With ``eq_f32`` / ``ec_f32`` (the float32 embeddings the unit rows were made from) the returned scores are the
     reference's ``F.cosine_similarity`` of the float32 rows (/root/reference/src/pipeline/search_pipeline.py:76-78) and the
     order is exact for them; without, the inner product of the unit rows as stored.  ``return_status`` adds an int32 [Q]
     tensor: 0 = first pass, 1 = widened, 2 = brute force (include/tsim.h).  1 <= k <= 64, d <= 768."""
     _need_gpu(eq_unit, ec_unit)
-    if eq_unit.dtype != torch.bfloat16 or ec_unit.dtype != torch.bfloat16:
-        raise ValueError("cosine_topk expects bf16 unit rows from l2norm_rows")
+    if eq_unit.dtype != UNIT_DTYPE or ec_unit.dtype != UNIT_DTYPE:
+        raise ValueError("cosine_topk expects float16 unit rows from l2norm_rows")
     ld = pad_dim(d)
     if eq_unit.shape[1] != ld or ec_unit.shape[1] != ld or not eq_unit.is_contiguous() or not ec_unit.is_contiguous():
         raise ValueError(f"cosine_topk: rows must be contiguous with stride pad_dim({d})={ld}")

@@ -39,7 +39,7 @@ class ClusteringPipeline(Pipeline):
         emb = emb.float().contiguous()
         n, d = emb.shape
         k = min(self.n_clusters, n)
-        unit = ops.l2norm_rows(emb)                                   # bf16 [n, ld]
+        unit = ops.l2norm_rows(emb)                                   # float16 [n, ld]
         x = unit[:, :d].float()
         g = torch.Generator(device="cpu").manual_seed(self.seed)
         # k-means++ seeding on (a sample of) the points, cosine distance

@@ -62,7 +62,7 @@ class SentenceMiningPipeline(SearchPipeline):
     def search_tensors(self, query_embeddings: torch.Tensor, corpus=None, max_num_results: int = 10):
         """Device-level search: returns (scores [Q,k] f32, indices [Q,k] i64) over the whole corpus.  Scores are the
         reference's ``F.cosine_similarity`` of the float32 embeddings (search_pipeline.py:76-77) and the order is exact for
-        them: bf16 unit rows feed the MFMA kernel for candidate selection only.  1 <= max_num_results <= 64, width <= 768."""
+        them: half-precision unit rows feed the MFMA kernel for candidate selection only.  1 <= max_num_results <= 64, width <= 768."""
         corpus = self.corpus if corpus is None else corpus
         n = len(corpus)
         d = query_embeddings.shape[1]

@@ -165,6 +165,8 @@ void tsim_encoder_destroy(tsim_encoder *enc);
 /* Forward on PACKED tokens (no padding work): token t of sequence b lives at cu_seqlens[b] <= t <
  * cu_seqlens[b+1]; tok_ids/tok_pos int32 [T] (tok_pos = position-embedding row, tok_col = column of the
  * token in the padded batch, used for MPNet's relative bias; pass tok_col = NULL to use tok_pos).
+ * max_len = the longest sequence of the batch (sizes the attention grid); max_len (+ pad_id + 1 for MPNet, whose position
+ * rows start there) must not exceed max_pos, else TSIM_EINVAL.
  * Outputs (either may be NULL): pooled_f32 [B, hidden] = masked mean-pool (A4), un-normalised like the
  * reference's encode_text; unit_f16 [B, ld_unit] = L2-normalised half rows ready for tsim_cosine_topk;
  * last_hidden_bf16 [T, hidden] for tests. */
@@ -172,6 +174,15 @@ int tsim_encoder_forward(tsim_encoder *enc, const int32_t *tok_ids, const int32_
                          const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
                          int32_t max_len, float *pooled_f32, void *unit_f16, int ld_unit,
                          void *last_hidden_bf16, void *stream);
+
+/* Kernels cannot raise HF's IndexError: a token id outside [0, vocab), a position row outside [0, max_pos) or a token whose
+ * column is >= the max_len passed to tsim_encoder_forward is clamped / computed anyway and leaves a bit in a per-encoder
+ * flag word.  This call copies the word to *flags_host, clears it and SYNCHRONISES `stream` (the only entry point that
+ * does): 0 = every forward since the last call was clean.  The Python wrappers call it at the end of encode_text. */
+#define TSIM_ENC_ERR_TOKEN_ID 1
+#define TSIM_ENC_ERR_POSITION 2
+#define TSIM_ENC_ERR_MAX_LEN 4
+int tsim_encoder_error_flags(tsim_encoder *enc, int32_t *flags_host, void *stream);
 
 #ifdef __cplusplus
 }

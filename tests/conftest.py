@@ -13,6 +13,16 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests (tests/test_sharded_gpu.py) start their ranks from multiprocessing's fork server.  It has to
+    # exist BEFORE this process initialises HIP: a process that holds the GPU must not fork+exec on the GPU boxes, and the
+    # server (started here, by one exec from a still GPU-free pytest) forks every later child from its own clean image.
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    try:
+        mp.set_forkserver_preload([])
+        forkserver.ensure_running()
+    except Exception as exc:   # the CPU suite does not need it
+        print(f"[conftest] fork server not started: {exc}")
 
 
 def golden(name):

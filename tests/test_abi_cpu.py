@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from text_similarity_amd import _lib, ops
+from text_similarity_amd import _lib, ops, presets
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -124,3 +124,17 @@ def test_hf_directory_round_trip_and_config_validation(tmp_path):
                         "num_attention_heads": 4, "intermediate_size": 128, "vocab_size": 10, "max_position_embeddings": 8})
     with pytest.raises(FileNotFoundError):
         load_hf_dir(str(tmp_path / "nope"))
+
+
+def test_position_table_guard_matches_hf_index_error():
+    """HF raises IndexError when a sequence needs a position row beyond the table: BERT rows 0..len-1, MPNet
+    rows pad_id+1..pad_id+len, so max_pos 514 holds 512 tokens and a 513- or 514-token sequence must be refused before
+    any launch.  Out-of-range token ids are clamped on the device and reported by NativeEncoder.check() (GPU test)."""
+    from text_similarity_amd.native_encoder import NativeEncoder
+    mp_cfg, bert_cfg = presets.PRESETS["all-mpnet-base-v2"], presets.PRESETS["bert-base-uncased"]
+    assert (mp_cfg.max_pos, mp_cfg.pad_id, bert_cfg.max_pos) == (514, 1, 512)
+    NativeEncoder.check_lengths(mp_cfg, 512)
+    NativeEncoder.check_lengths(bert_cfg, 512)
+    for cfg, n in ((mp_cfg, 513), (mp_cfg, 514), (bert_cfg, 513)):
+        with pytest.raises(ValueError):
+            NativeEncoder.check_lengths(cfg, n)

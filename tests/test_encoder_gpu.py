@@ -240,3 +240,63 @@ def test_large_batch_equals_small_batches_bitwise(preset, wdtype):
         c = (cu[s:s + 49] - cu[s]).astype(np.int32)
         small = enc.forward_packed(torch.from_numpy(f).to(DEV), torch.from_numpy(c).to(DEV))["pooled"]
         assert torch.equal(small, big[rows]), f"{preset}/{wdtype}: rows {s}.. differ between batch sizes"
+
+
+def test_out_of_range_inputs_are_clamped_flagged_and_refused():
+    """HF raises IndexError for a token id / position id outside its table; the kernels clamp the index (no read outside
+    the tables, no fault) and NativeEncoder.check() reports it.  Sequences that need position rows beyond the table are
+    refused before any launch (MPNet: 513 tokens)."""
+    preset = "tiny-mpnet"
+    cfg = presets.PRESETS[preset]
+    enc = NativeEncoder.from_preset(preset, max_tokens=4096, max_seqs=8)
+    ids = presets.randint("oob/ids", 40, 5, cfg.vocab).astype(np.int32)
+    cu = torch.tensor([0, 17, 40], dtype=torch.int32, device=DEV)
+    good = enc.forward_packed(torch.from_numpy(ids).to(DEV), cu)["pooled"]
+    enc.check()                                                    # clean input: nothing flagged
+    bad = ids.copy()
+    bad[5] = cfg.vocab + 1000                                      # tokenizer / vocabulary mismatch
+    bad[20] = -3
+    out = enc.forward_packed(torch.from_numpy(bad).to(DEV), cu)["pooled"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    with pytest.raises(IndexError, match="token id"):
+        enc.check()
+    enc.check()                                                    # the flag word was cleared by the failed check
+    # a caller-supplied max_len smaller than the longest sequence would leave attention blocks unvisited: flagged
+    enc.forward_packed(torch.from_numpy(ids).to(DEV), cu, max_len=10)
+    with pytest.raises(IndexError, match="max_len"):
+        enc.check()
+    # position rows beyond the table: refused on the host
+    n = cfg.max_pos - cfg.pad_id       # one token more than the table holds for MPNet
+    long_ids = torch.from_numpy(presets.randint("oob/long", n, 5, cfg.vocab).astype(np.int32)).to(DEV)
+    big = NativeEncoder.from_preset(preset, max_tokens=n, max_seqs=1)
+    with pytest.raises(ValueError, match="position rows"):
+        big.forward_packed(long_ids, torch.tensor([0, n], dtype=torch.int32, device=DEV))
+    ok = big.forward_packed(long_ids[:n - 1], torch.tensor([0, n - 1], dtype=torch.int32, device=DEV))["pooled"]
+    big.check()
+    assert torch.isfinite(ok).all() and torch.equal(good, enc.forward_packed(torch.from_numpy(ids).to(DEV), cu)["pooled"])
+
+
+def test_save_pretrained_round_trip(tmp_path):
+    """modeling.py:52-59: save_pretrained writes the encoder weights (+ tokenizer + parameters); from_pretrained on that
+    directory gives a model with bit-identical outputs."""
+    from transformers import BertTokenizer
+    from text_similarity_amd.configurations.config import Configuration, ModelParameters
+    from text_similarity_amd.models.sentence_encoder import SentenceTransformerWrapper
+    preset = "tiny-bert"
+    tok = BertTokenizer(vocab=presets.synthetic_vocab(1000), do_lower_case=True)
+    params = Configuration(model_parameters=ModelParameters(preset, hidden_size=64), model=preset, save_path="",
+                           tokenizer=tok, device=torch.device(DEV), batch_size=4, max_tokens_per_batch=2048,
+                           max_seqs_per_batch=64, sequence_max_len=48)      # tiny-bert has 64 position rows
+    model = SentenceTransformerWrapper.from_preset(preset, params, parallel_mode=False)
+    sents = presets.synthetic_sentences(40, seed="save/s", vocab_size=1000)
+    a = model.encode_text(sents)
+    model.save_pretrained(str(tmp_path))
+    for f in ("config.json", "model.safetensors", "model_config.bin"):
+        assert (tmp_path / f).exists(), f
+    assert any((tmp_path / f).exists() for f in ("vocab.txt", "tokenizer.json", "tokenizer_config.json"))   # tokenizer files
+    cfgd = torch.load(str(tmp_path / "model_config.bin"), weights_only=True)
+    assert cfgd["batch_size"] == 4 and cfgd["model_parameters"]["hidden_size"] == 64
+    again = SentenceTransformerWrapper.from_pretrained(str(tmp_path), params=params, parallel_mode=False)
+    assert torch.equal(a, again.encode_text(sents))
+    assert model.last_encode_stats["sentences"] == 40 and model.last_encode_stats["wall_s"] > 0

@@ -64,6 +64,7 @@ _SIGS = {
     "tsim_encoder_create": (C.c_int, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC),
                                       C.POINTER(C.c_void_p)]),
     "tsim_encoder_destroy": (None, [C.c_void_p]),
+    "tsim_encoder_error_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "tsim_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p]),

@@ -36,12 +36,23 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
                                                        const float *__restrict__ type0,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, float eps, int T, int H,
-                                                       bf16_t *__restrict__ out) {
+                                                       bf16_t *__restrict__ out, int vocab, int max_pos,
+                                                       const int32_t *__restrict__ col, int max_len,
+                                                       int *__restrict__ err_flags) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const float *w = word + (int64_t)ids[t] * H;
-    const float *p = pos_emb + (int64_t)pos[t] * H;
+    // HF raises IndexError on an id / position outside its table; a kernel cannot, so the index is clamped (no read
+    // outside the tables) and an error bit is left for tsim_encoder_error_flags.  A token whose column is >= the max_len
+    // the caller promised would be skipped by the attention grid: flagged as well.
+    int id = ids[t], ps = pos[t];
+    int bad = 0;
+    if (id < 0 || id >= vocab) { bad |= TSIM_ENC_ERR_TOKEN_ID; id = id < 0 ? 0 : vocab - 1; }
+    if (ps < 0 || ps >= max_pos) { bad |= TSIM_ENC_ERR_POSITION; ps = ps < 0 ? 0 : max_pos - 1; }
+    if (col[t] >= max_len || col[t] < 0) bad |= TSIM_ENC_ERR_MAX_LEN;
+    if (bad && lane == 0) atomicOr(err_flags, bad);
+    const float *w = word + (int64_t)id * H;
+    const float *p = pos_emb + (int64_t)ps * H;
     float v[VPL];
     float s = 0.f;
 #pragma unroll
@@ -850,6 +861,7 @@ struct tsim_encoder {
     bf16_t *x0 = nullptr, *x1 = nullptr, *qkv = nullptr, *ctx = nullptr, *h1 = nullptr;
     float *ybuf = nullptr;   // fp32 pre-LayerNorm sums (wide models only)
     uint8_t *aq = nullptr, *as = nullptr, *hq = nullptr, *hs = nullptr;   // MXFP8 images of a projection's input ([Tp,H] / [Tp,F])
+    int *err_flags = nullptr;   // TSIM_ENC_ERR_* bits raised by kernels since the last tsim_encoder_error_flags
 };
 
 namespace tsim {
@@ -1146,8 +1158,19 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
             if (hipMemset(*a.p, 0, a.n) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
         }
     }
+    if ((rc = dev_alloc(e, 256, (void **)&e->err_flags))) return bail(rc);
+    if (hipMemset(e->err_flags, 0, 256) != hipSuccess) return bail(fail(TSIM_EHIP, "hipMemset failed"));
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(TSIM_EHIP, "sync after upload failed"));
     *out = e;
+    return TSIM_OK;
+}
+
+extern "C" int tsim_encoder_error_flags(tsim_encoder *e, int32_t *flags_host, void *stream) {
+    TSIM_REQUIRE(e && flags_host, "encoder_error_flags: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    TSIM_HIP_CHECK(hipMemcpyAsync(flags_host, e->err_flags, 4, hipMemcpyDeviceToHost, st));
+    TSIM_HIP_CHECK(hipMemsetAsync(e->err_flags, 0, 4, st));
+    TSIM_HIP_CHECK(hipStreamSynchronize(st));
     return TSIM_OK;
 }
 
@@ -1188,7 +1211,11 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     TSIM_REQUIRE(e && cu_seqlens && (T == 0 || (tok_ids && tok_pos)), "encoder_forward: null pointer");   // T = 0: only empty sequences
     TSIM_REQUIRE(T >= 0 && B >= 0 && T <= e->cfg.max_tokens && B <= e->cfg.max_seqs,
                  "encoder_forward: T=%d B=%d exceed capacity (%d tokens, %d sequences)", T, B, e->cfg.max_tokens, e->cfg.max_seqs);
-    TSIM_REQUIRE(max_len <= e->cfg.max_pos, "encoder_forward: max_len=%d > max_pos=%d", max_len, e->cfg.max_pos);
+    // position rows: BERT uses 0 .. len-1, MPNet pad_id+1 .. pad_id+len (modeling_mpnet create_position_ids_from_input_ids)
+    const int pos_span = max_len + (e->cfg.arch == TSIM_ARCH_MPNET ? e->cfg.pad_id + 1 : 0);
+    TSIM_REQUIRE(max_len >= 0 && pos_span <= e->cfg.max_pos,
+                 "encoder_forward: sequences of %d tokens need position rows up to %d, the table has %d", max_len, pos_span - 1,
+                 e->cfg.max_pos);
     TSIM_REQUIRE(!unit_bf16 || ld_unit >= e->cfg.hidden, "encoder_forward: ld_unit < hidden");
     if (B == 0) return TSIM_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1198,7 +1225,10 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     int rc;
     if (T > 0) {
         const unsigned g = (unsigned)((T + 3) / 4);
-#define EMBED(V) hipLaunchKernelGGL(embed_ln_kernel<V>, dim3(g), dim3(256), 0, st, tok_ids, tok_pos, e->word, e->pos, e->type0, e->emb_g, e->emb_b, c.ln_eps, T, H, e->x0)
+        // column of a token inside its sequence: tok_col when given (MPNet), else tok_pos (BERT: position == column)
+        const int32_t *colp = tok_col ? tok_col : tok_pos;
+        const int col_limit = tok_col || c.arch == TSIM_ARCH_BERT ? max_len : c.max_pos;   // MPNet without tok_col: pos is not a column
+#define EMBED(V) hipLaunchKernelGGL(embed_ln_kernel<V>, dim3(g), dim3(256), 0, st, tok_ids, tok_pos, e->word, e->pos, e->type0, e->emb_g, e->emb_b, c.ln_eps, T, H, e->x0, c.vocab, c.max_pos, colp, col_limit, e->err_flags)
         if (H == 64) EMBED(1); else if (H == 384) EMBED(6); else EMBED(12);
 #undef EMBED
         TSIM_HIP_CHECK(hipGetLastError());

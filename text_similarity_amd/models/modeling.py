@@ -26,9 +26,17 @@ class BaseEncoderModel(nn.Module):
         return cls(params=params, context_embedder=_native_from_dir(path, params))
 
     def save_pretrained(self, path):
+        """modeling.py:52-59: encoder weights, tokenizer files and the model parameters under ``path``.  The reference
+        pickles ``self.params`` into model_config.bin; here the same file holds a plain dict of the primitive fields
+        (``torch.load(..., weights_only=True)`` reads it) — device handles and the tokenizer object are not serialised."""
         assert path is not None
-        os.makedirs(path, exist_ok=True)
-        raise NotImplementedError("weights live in the native handle as bf16; keep the source checkpoint directory")
+        if not os.path.exists(path):
+            os.makedirs(path)
+        self.context_embedder.save_pretrained(path)
+        tok = getattr(self.params, "tokenizer", None)
+        if tok is not None and hasattr(tok, "save_pretrained"):
+            tok.save_pretrained(path)
+        torch.save(_plain_params(self.params), os.path.join(path, "model_config.bin"))
 
     @property
     def model_name(self):
@@ -55,6 +63,18 @@ class BaseEncoderModel(nn.Module):
 
     def encode(self):
         raise NotImplementedError()
+
+
+def _plain_params(params) -> dict:
+    out = {}
+    for k, v in vars(params).items():
+        if isinstance(v, (int, float, str, bool, type(None))):
+            out[k] = v
+        elif k == "device":
+            out[k] = str(v)
+        elif k == "model_parameters" and v is not None:
+            out[k] = {kk: vv for kk, vv in vars(v).items() if isinstance(vv, (int, float, str, bool, type(None)))}
+    return out
 
 
 def _native_from_dir(path, params) -> NativeEncoder:

@@ -49,12 +49,13 @@ class _EncodeMixin:
         pooler = getattr(self, "pooler", None) or AvgPoolingStrategy(self.params)
         return self.projection(pooler(hidden, features))
 
-    def encode_packed(self, flat_ids: torch.Tensor, cu: torch.Tensor, unit: bool = False):
-        """Device-resident pre-tokenised input (the benchmark path): pooled f32 [B,H] (+ unit float16 rows)."""
+    def encode_packed(self, flat_ids: torch.Tensor, cu: torch.Tensor, unit: bool = False, cu_host: np.ndarray = None):
+        """Device-resident pre-tokenised input (the benchmark path): pooled f32 [B,H] (+ unit float16 rows).
+        ``cu_host``: the same offsets on the host, when the caller has them (saves a device->host copy and its sync)."""
         enc: NativeEncoder = self.context_embedder
         B = cu.numel() - 1
         outs, units = [], []
-        cu_h = cu.cpu().numpy().astype(np.int64)
+        cu_h = (cu.cpu().numpy() if cu_host is None else np.asarray(cu_host)).astype(np.int64)
         s = 0
         while s < B:
             e = s + 1
@@ -73,26 +74,48 @@ class _EncodeMixin:
 
     def encode_text(self, documents: List[str], output_np: bool = False) -> Union[torch.Tensor, np.ndarray]:
         """sentence_encoder.py:136-173: sort by character length, encode in batches, un-sort, stack.
-        Returns float32 [N, H] on params.device (or numpy when ``output_np``), un-normalised."""
+        Returns float32 [N, H] on params.device (or numpy when ``output_np``), un-normalised.
+        The host tokenizer is the end-to-end bottleneck of this path, so it runs one chunk AHEAD on a
+        host thread: chunk i+1 is tokenised while the GPU encodes chunk i (kernel launches are asynchronous; fast
+        tokenizers release the GIL).  ``self.last_encode_stats`` holds the split of the wall time."""
+        import time
+        from concurrent.futures import ThreadPoolExecutor
         enc: NativeEncoder = self.context_embedder
         dev = enc.device
         n = len(documents)
         if n == 0:
             out = torch.empty((0, enc.cfg.hidden), dtype=torch.float32, device=dev)
             return out.cpu().numpy() if output_np else out
+        t_start = time.perf_counter()
         order = np.argsort([len(s) for s in documents], kind="stable")
         docs = [documents[i] for i in order]
-        flat, lens = _tokenize_packed(self.params.tokenizer, docs, self.params.sequence_max_len,
-                                      max(int(self.params.batch_size), 1) * 64)
-        cu = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(lens, out=cu[1:])
-        flat_d = torch.from_numpy(flat).to(dev)
-        cu_d = torch.from_numpy(cu.astype(np.int32)).to(dev)
-        with torch.no_grad():
-            pooled = self.encode_packed(flat_d, cu_d)
-            pooled = self.projection(pooled)
+        tok_batch = max(int(self.params.batch_size), 1) * 64
+        chunk = max(tok_batch, int(getattr(self.params, "encode_chunk_sentences", 8192)))
+        t_tok = [0.0]
+
+        def tokenize(lo):
+            t0 = time.perf_counter()
+            r = _tokenize_packed(self.params.tokenizer, docs[lo:lo + chunk], self.params.sequence_max_len, tok_batch)
+            t_tok[0] += time.perf_counter() - t0
+            return r
+
+        parts = []
+        with ThreadPoolExecutor(max_workers=1) as pool, torch.no_grad():
+            fut = pool.submit(tokenize, 0)
+            for lo in range(0, n, chunk):
+                flat, lens = fut.result()
+                if lo + chunk < n:
+                    fut = pool.submit(tokenize, lo + chunk)
+                cu = np.zeros(len(lens) + 1, dtype=np.int64)
+                np.cumsum(lens, out=cu[1:])
+                flat_d = torch.from_numpy(flat).to(dev, non_blocking=True)
+                cu_d = torch.from_numpy(cu.astype(np.int32)).to(dev, non_blocking=True)
+                parts.append(self.projection(self.encode_packed(flat_d, cu_d, cu_host=cu)))
+        pooled = torch.cat(parts) if len(parts) > 1 else parts[0]
         out = torch.empty_like(pooled)
         out[torch.from_numpy(order).to(dev)] = pooled      # un-sort (sentence_encoder.py:168)
+        enc.check()      # out-of-range ids / positions: HF would have raised IndexError (synchronises, as the return would)
+        self.last_encode_stats = {"sentences": n, "wall_s": time.perf_counter() - t_start, "tokenizer_s": t_tok[0]}
         return out.cpu().numpy() if output_np else out
 
     def get_sentence_embedding_dimension(self):

@@ -97,7 +97,7 @@ class NativeEncoder:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().tsim_encoder_create(C.byref(cc), C.byref(ew), C.byref(handle)), "encoder_create")
         self._h = handle
-        self._keep = None  # host copies are not needed after upload
+        self._weights_host = w  # float32 source weights: what save_pretrained writes (the handle holds bf16 / fp8 copies)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -112,6 +112,12 @@ class NativeEncoder:
         cfg, w = load_hf_dir(path)
         return cls(cfg, w, **kw)
 
+    def save_pretrained(self, path: str) -> None:
+        """config.json + model.safetensors of the float32 source weights (what ``from_pretrained(path)`` reads back) — the
+        ``context_embedder.save_pretrained(path)`` of /root/reference/src/models/modeling.py:56."""
+        from .weights import save_hf_dir
+        save_hf_dir(path, self.cfg, self._weights_host)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
@@ -119,6 +125,30 @@ class NativeEncoder:
                 _lib.lib().tsim_encoder_destroy(h)
             except Exception:
                 pass
+
+    # ------------------------------------------------------------------ input validation
+    ERR_BITS = {1: "a token id outside [0, vocab_size)", 2: "a position id outside the position table",
+                4: "a sequence longer than the max_len passed to forward_packed"}
+
+    @staticmethod
+    def check_lengths(cfg: EncoderConfig, max_len: int) -> None:
+        """HF raises IndexError when a sequence needs a position row the table does not have: BERT rows 0..len-1, MPNet
+        rows pad_id+1..pad_id+len (max_pos 514 holds 512 tokens).  Raised here, before any launch."""
+        need = int(max_len) + (cfg.pad_id + 1 if cfg.arch == "mpnet" else 0)
+        if need > cfg.max_pos:
+            raise ValueError(f"sequences of {max_len} tokens need position rows up to {need - 1}; "
+                             f"{cfg.arch} table has {cfg.max_pos} (max {cfg.max_pos - need + int(max_len)} tokens)")
+
+    def check(self) -> None:
+        """Raise if any forward since the last check saw an out-of-range token id / position id or a sequence longer than
+        its promised max_len (the kernels clamp and go on; HF would have raised IndexError).  Synchronises the stream."""
+        flags = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tsim_encoder_error_flags(self._h, C.byref(flags),
+                                                           torch.cuda.current_stream(self.device).cuda_stream), "encoder_error_flags")
+        if flags.value:
+            what = "; ".join(msg for bit, msg in self.ERR_BITS.items() if flags.value & bit)
+            raise IndexError(f"encoder input out of range: {what}")
 
     # torch.nn.Module-ish no-ops used by the reference wrappers (`self.to(device)`, `self.eval()`)
     def to(self, *a, **k):
@@ -168,18 +198,20 @@ class NativeEncoder:
         cols = None if cols is None else cols.to(torch.int32).contiguous()
         if max_len is None:   # longest sequence in the batch: sizes the attention grid (one host sync; pass it to avoid)
             max_len = int((cu[1:] - cu[:-1]).max().item()) if B else 0
+        self.check_lengths(self.cfg, max_len)
         H = self.cfg.hidden
         out = {}
         dev = flat_ids.device
         p = torch.empty((B, H), dtype=torch.float32, device=dev) if pooled else None
         u = torch.empty((B, ops.pad_dim(H)), dtype=ops.UNIT_DTYPE, device=dev) if unit else None
         hd = torch.empty((T, H), dtype=torch.bfloat16, device=dev) if hidden else None
-        _lib.check(_lib.lib().tsim_encoder_forward(
-            self._h, flat_ids.data_ptr(), pos.data_ptr(), cols.data_ptr() if cols is not None else None,
-            cu.data_ptr(), T, B, int(max_len), p.data_ptr() if p is not None else None,
-            u.data_ptr() if u is not None else None, u.shape[1] if u is not None else 0,
-            hd.data_ptr() if hd is not None else None, torch.cuda.current_stream(dev).cuda_stream),
-            "encoder_forward")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tsim_encoder_forward(
+                self._h, flat_ids.data_ptr(), pos.data_ptr(), cols.data_ptr() if cols is not None else None,
+                cu.data_ptr(), T, B, int(max_len), p.data_ptr() if p is not None else None,
+                u.data_ptr() if u is not None else None, u.shape[1] if u is not None else 0,
+                hd.data_ptr() if hd is not None else None, torch.cuda.current_stream(dev).cuda_stream),
+                "encoder_forward")
         if pooled:
             out["pooled"] = p
         if unit:

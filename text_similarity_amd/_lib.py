@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsim.so")
+LIB_PATH = os.environ.get("TSIM_LIB") or os.path.join(_HERE, "libtsim.so")   # TSIM_LIB: a variant build (build.py TSIM_BUILD_TAG)
 
 TSIM_F32, TSIM_BF16 = 0, 1
 ARCH_BERT, ARCH_MPNET = 0, 1

@@ -13,9 +13,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "libtsim.so")
-SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip"]
+# TSIM_BUILD_TAG=<tag>: a variant build beside the product (objects in csrc/_obj_<tag>, library libtsim_<tag>.so; load it with
+# TSIM_LIB=<path>).  Used for the diagnostic builds with in-kernel stamps and for A/B variants shipped to the GPU box together.
+TAG = os.environ.get("TSIM_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libtsim" + ("_" + TAG if TAG else "") + ".so")
+SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_d384.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip"]
 HOT_KERNELS = ("cos_topk_partial", "gemm_bf16", "gemm_xres", "gemm_pp", "attention_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
@@ -25,7 +28,8 @@ def _newer(a, bs):
     return os.path.exists(a) and all(os.path.getmtime(a) >= os.path.getmtime(b) for b in bs)
 
 
-def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=(), only=None) -> str:
+    """``only``: compile just these sources (the others must have objects already) — quick iteration on one kernel."""
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "tsim.h"))
@@ -34,6 +38,10 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
     for s in srcs:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        if only is not None and s not in only:
+            if not os.path.exists(obj):
+                raise RuntimeError(f"--only: {obj} does not exist yet")
+            continue
         if force or not _newer(obj, [src] + hdrs):
             jobs.append((src, obj))
 
@@ -91,6 +99,7 @@ if __name__ == "__main__":
     # --stamps: DIAGNOSTIC build of the ping-pong GEMM with in-kernel cycle stamps (tools/pp_stamps.py); rebuild without it after
     # -DNAME arguments are passed through to hipcc (A/B builds of compile-time variants; they force a rebuild)
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
     build(force="--force" in sys.argv or "--stamps" in sys.argv or bool(defs),
-          extra_flags=(["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else []) + defs)
+          extra_flags=(["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else []) + defs, only=only or None)
     print(LIB)

@@ -3,7 +3,7 @@
 
 namespace tsim {
 int k1_launch_kl32(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
-                   float *part_s, int *part_i, int *gthr, hipStream_t st) {
-    return launch_k1_kl<32>(p, D, eq, Q, ec, N, part_s, part_i, gthr, st);
+                   float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect range) {
+    return launch_k1_kl<32>(p, D, eq, Q, ec, N, part_s, part_i, gthr, st, range);
 }
 }  // namespace tsim

@@ -98,10 +98,15 @@ constexpr int k1_lds_bytes() {
 // DIAGNOSTIC build only (python -m text_similarity_amd.build --stamps; tools/pp_stamps.py --search): cycles of wave 0 of every
 // workgroup of the main pass: [0] tile pairs, [1] wait for the pair's DMA, [2] barrier, [3] DMA issue, [4] fragment reads +
 // MFMAs + selection, [5] prologue (query fragments, thresholds), [6] epilogue (drain, list write-out), [7] workgroups.
-static __device__ unsigned long long g_k1_stamps[8];
+// Ping-pong schedule: [8..15] wave 0 (group 0) and [16..23] wave 4 (group 1) of every workgroup: +0 tiles, +1 L sections
+// that carry the filter and the DMA issue, +2 the other L sections, +3 barrier after L, +4 M sections, +5 barrier after M,
+// +6 whole loop.
+#define K1_NSTAMPS 24
+static __device__ unsigned long long g_k1_stamps[K1_NSTAMPS];
 #define K1_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
 #define K1_STAMP(v) do { } while (0)
+#define K1_NSTAMPS 0
 #endif
 
 template <int... I, class F>
@@ -128,9 +133,27 @@ struct K1Collect {
     unsigned long long *buf;     // [Q][cap] entries: score bits | (uint64)(shard row) << 32
     int *cnt;                    // [Q] entries appended per slot (may exceed cap)
     int cap;
+    // list kernels launched over a ROW RANGE of the shard (two-phase main pass, search.hip): this launch's lists are
+    // p2_base .. of the query's p2_total lists, and its rows start at shard row row_base.  All zero: one launch, whole shard.
+    int p2_base, p2_total, row_base;
 };
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false>
+// PP = two-group ping-pong schedule of the tile loop (8 waves, QW = 1): the waves form two groups of four, one wave of each
+// group per SIMD, running the SAME program one barrier interval apart.  A wave alternates between M — the tile's 24-MFMA
+// stream with its own fragment reads rolling four k-steps ahead — and L — everything else: the selection filter of the tile
+// it has just scored and the LDS-DMA issue of the tile after next:
+//   group 0 : M(t) | L(t) | M(t+1) | L(t+1) ...
+//   group 1 :  -   | M(t) |  L(t)  | M(t+1) ...
+// so in every interval exactly one wave per SIMD feeds the matrix pipe and its partner's VALU / branches / DMA issue run
+// beside it.  Under the common-barrier schedules the two waves of a SIMD raced instead: the older one ran its MFMAs nearly
+// alone, then idled at the barrier while the younger ran with its LDS latencies exposed (5 725 cycles per tile pair for
+// 3 072 of MFMA work: profiles/README.md).  (A first form that cut the tile into 12-MFMA sections with register-held
+// fragments — L = 12 ds_read_b128 + side work, M = 12 MFMAs — measured 8 % SLOWER than PAIR: its L sections took ~600
+// cycles against 384 of MFMA.)
+// Ring: three tile slots; tile t+2 is issued in L(t): its slot held tile t-1, last read in group 1's M(t-1), two barriers
+// earlier for either group.  Tile t+1 must have landed when group 0 starts M(t+1): group 0 waits for its pieces at the end
+// of L(t) (vmcnt(PPW): t+2 stays in flight), group 1 at the end of M(t) (vmcnt(0): it has not issued t+2 yet).
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false, bool PP = false>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const unit_t *__restrict__ eq, int Q, const unit_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
@@ -335,6 +358,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             return;
         }
         if (__any(m > thr[u])) {
+#ifdef TSIM_PP_STAMPS
+            if (threadIdx.x == 0) atomicAdd(&g_k1_stamps[7 + 8], 1ull);   // [15]: candidate events seen by wave 0
+#endif
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
 #ifndef TSIM_K1_FLAT_SCAN
@@ -432,7 +458,101 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     unsigned long long ks_n = 0, ks_dma = 0, ks_bar = 0, ks_iss = 0, ks_cmp = 0;
     const unsigned long long ks_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (PAIR) {
+    if constexpr (PP) {
+        static_assert(!PAIR && QW == 1 && NWAVES == 8 && KL <= 16, "ping-pong schedule: 8 waves, one query set per wave");
+        const int grp = wave >> 2;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+        uint32_t abase[8];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) abase[bb] = lds0 + aoff[bb];
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        issue_tile(2, 2);
+        wait_vmcnt<2 * PPW>();          // my pieces of tile 0 (tiles 1 and 2 stay in flight)
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();       // group 1 runs one interval behind group 0
+#ifdef TSIM_PP_STAMPS
+        unsigned long long pl0 = 0, pl1 = 0, pb1 = 0, pm = 0, pb2 = 0;
+        const unsigned long long pp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        auto do_tile = [&](int t, auto stc) __attribute__((always_inline)) {
+            constexpr int stage = decltype(stc)::value;
+            K1_STAMP(q0);
+            // ---------------- M: the tile's MFMA stream with its own fragment reads rolling PF k-steps ahead (counted lgkmcnt)
+            if (wave_on) {
+#ifndef TSIM_K1_PP_PF
+#define TSIM_K1_PP_PF 8
+#endif
+                // alone on the SIMD's matrix pipe, the stream is paced by LDS latency / PF: 4 reads in flight gave 42 cycles
+                // per k-step (1 000 per tile for 768 of MFMA work), so the reads roll 8 k-steps (256 pipe cycles) ahead here
+                constexpr int PF = TSIM_K1_PP_PF;
+                k1_u32x4 fr[PF + 1];
+                auto rd = [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int n = decltype(nc)::value;
+                    k1_lds_read<stage * STAGE_BYTES + (n >> 3) * 256>(fr[n % (PF + 1)], abase[n & 7]);
+                };
+                __builtin_amdgcn_s_setprio(1);
+                k1_static_for(std::make_integer_sequence<int, PF>{}, rd);
+                k1_static_for(std::make_integer_sequence<int, KSTEPS>{}, [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int sidx = decltype(sc)::value;
+                    if constexpr (sidx + PF < KSTEPS) rd(std::integral_constant<int, sidx + PF>{});
+                    constexpr int younger = sidx + PF < KSTEPS ? PF : KSTEPS - 1 - sidx;
+                    k1_lgkm_wait<younger>(fr[sidx % (PF + 1)]);
+                    if constexpr (sidx == 0)   // srcC = inline constant 0: no register clear per tile
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[0]), bq[0][0], f32x16{}, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[sidx % (PF + 1)]), bq[0][sidx],
+                                                                     acc, 0, 0, 0);
+                });
+                asm volatile("" : "+v"(acc));      // keep the stream inside its barrier interval
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (grp == 1) wait_vmcnt<0>();         // group 1: its pieces of tile t+1 are all it has in flight here
+            K1_STAMP(q1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            K1_STAMP(q2);
+            // ---------------- L: selection filter of the tile just scored + LDS-DMA issue of tile t+2, beside the partner's M.
+            // Slot (stage+2)%3 held tile t-1: last read in group 1's M(t-1), two barriers ago for either group.
+            if (wave_on) filter(std::integral_constant<int, 0>{}, acc, t);
+            K1_STAMP(q2f);
+            if (t >= 1) issue_tile(t + 2, (stage + 2) % 3);
+            if (grp == 0) wait_vmcnt<PPW>();       // group 0: my pieces of tile t+1 (t+2 stays in flight)
+            K1_STAMP(q3);
+#ifdef TSIM_PP_STAMPS
+            pl1 += q2f - q2;
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef TSIM_PP_STAMPS
+            {
+                const unsigned long long q4 = __builtin_amdgcn_s_memtime();
+                pm += q1 - q0; pb1 += q2 - q1; pl0 += q3 - q2; pb2 += q4 - q3;
+            }
+#endif
+        };
+        int t = 0;
+        for (; t + 3 <= ntiles; t += 3) {
+            do_tile(t, std::integral_constant<int, 0>{});
+            do_tile(t + 1, std::integral_constant<int, 1>{});
+            do_tile(t + 2, std::integral_constant<int, 2>{});
+        }
+        if (t < ntiles) do_tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) do_tile(t + 1, std::integral_constant<int, 1>{});
+        if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with group 1's first barrier
+#ifdef TSIM_PP_STAMPS
+        (void)pl1;
+        if (!MAXONLY && !COLLECT && (threadIdx.x == 0 || threadIdx.x == 256)) {
+            const int o = threadIdx.x == 0 ? 8 : 16;
+            atomicAdd(&g_k1_stamps[o + 0], (unsigned long long)ntiles); atomicAdd(&g_k1_stamps[o + 1], pl0);
+            atomicAdd(&g_k1_stamps[o + 2], pl1); atomicAdd(&g_k1_stamps[o + 3], pb1); atomicAdd(&g_k1_stamps[o + 4], pm);
+            atomicAdd(&g_k1_stamps[o + 5], pb2); atomicAdd(&g_k1_stamps[o + 6], __builtin_amdgcn_s_memtime() - pp_t0);
+        }
+#endif
+    } else if constexpr (PAIR) {
         // stage = two tiles; stages alternate between slots {0,1} and {2,3}.  At the barrier of pair p everyone has
         // finished pair p-1, whose slots are exactly those of pair p+1, which is then issued and has one pair-time
         // (~48 MFMAs per wave) to land.
@@ -442,10 +562,24 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             K1_STAMP(s1);
             __builtin_amdgcn_s_barrier();
             K1_STAMP(s2);
-            issue_tile(t + 2, (slot + 2) & 3);
-            issue_tile(t + 3, (slot + 3) & 3);
+            // STAGGER (MI355X_MICROARCH.md "Two waves per SIMD" item 9): the two waves of a SIMD run the same program and would
+            // reach their MFMA streams, their LDS bursts and the barrier together; waves 4-7 (the partners of 0-3) issue the
+            // block's LDS-DMA BETWEEN its two tiles instead of at its head, which shifts their MFMA streams by the length of
+            // the issue (~440 cycles) against their partners'.
+#ifndef TSIM_K1_STAGGER
+#define TSIM_K1_STAGGER 1
+#endif
+            const bool late = TSIM_K1_STAGGER != 0 && wave >= 4;
+            if (!late) {
+                issue_tile(t + 2, (slot + 2) & 3);
+                issue_tile(t + 3, (slot + 3) & 3);
+            }
             K1_STAMP(s3);
             compute_tile(t, slot);
+            if (late) {
+                issue_tile(t + 2, (slot + 2) & 3);
+                issue_tile(t + 3, (slot + 3) & 3);
+            }
             if (t + 1 < ntiles) compute_tile(t + 1, slot + 1);
 #ifdef TSIM_PP_STAMPS
             {
@@ -483,18 +617,19 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #endif
 
     if (wave_on) {
-        const int P2 = nchunks * 2;
-        const int base = (int)row0;  // local -> shard row index (N < 2^31 enforced by the host)
+        const int P2 = coll.p2_total > 0 ? coll.p2_total : nchunks * 2;
+        const int pfirst = coll.p2_base;
+        const int base = (int)row0 + coll.row_base;  // local -> shard row index (N < 2^31 enforced by the host)
         auto flush = [&](auto uc) __attribute__((always_inline))  {
             constexpr int u = decltype(uc)::value;
             if constexpr (MAXONLY) {
-                if (q0 + 32 * u + r < Q) part_s[(int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h] = bmax[u];
+                if (q0 + 32 * u + r < Q) part_s[(int64_t)(q0 + 32 * u + r) * P2 + pfirst + chunk * 2 + h] = bmax[u];
                 return;
             }
             drain(uc);
             if constexpr (COLLECT) return;
             if (q0 + 32 * u + r < Q) {
-                const int64_t o = ((int64_t)(q0 + 32 * u + r) * P2 + chunk * 2 + h) * KL;
+                const int64_t o = ((int64_t)(q0 + 32 * u + r) * P2 + pfirst + chunk * 2 + h) * KL;
 #pragma unroll
                 for (int j = 0; j < KL; j += 4) {
                     *reinterpret_cast<float4 *>(part_s + o + j) =
@@ -576,12 +711,12 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false>
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false, bool PP = false>
 static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT>;
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP>;
     // the > 64 KiB dynamic-LDS opt-in is per device (a process may drive several GPUs): set it once per device
     static bool attr_done[64] = {};
     int dev = 0;
@@ -599,6 +734,11 @@ static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_
     return TSIM_OK;
 }
 
+// the headline shape (D = 384, KL = 16 main pass) lives in its own translation unit, k1_d384.hip: it is the kernel under
+// tuning, and one instantiation rebuilds in a minute instead of five
+int k1_launch_d384_kl16(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N, float *part_s,
+                        int *part_i, int *gthr, hipStream_t st, K1Collect coll);
+
 template <int KL, bool MAXONLY = false, bool COLLECT = false>
 static int launch_k1_kl(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                         float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
@@ -606,11 +746,10 @@ static int launch_k1_kl(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, c
         case 128: return launch_k1<128, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 256: return launch_k1<256, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 384: {
-            static int pair = -1;
-            if (pair < 0) { const char *e = getenv("TSIM_K1_PAIR"); pair = e ? atoi(e) : 1; }
             if constexpr (!MAXONLY && !COLLECT && KL == 16)
-                if (pair) return launch_k1<384, 8, 1, KL, MAXONLY, true>(p, eq, Q, ec, N, part_s, part_i, gthr, st);
-            return launch_k1<384, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+                return k1_launch_d384_kl16(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+            else
+                return launch_k1<384, 8, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         }
         case 512: return launch_k1<512, 4, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 768: return launch_k1<768, 4, 1, KL, MAXONLY, false, COLLECT>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
@@ -622,9 +761,9 @@ static int launch_k1_kl(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, c
 int k1_launch_blockmax(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                        float *bmax, hipStream_t st);
 int k1_launch_kl16(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
-                   float *part_s, int *part_i, int *gthr, hipStream_t st);
+                   float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect range = K1Collect{});
 int k1_launch_kl32(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
-                   float *part_s, int *part_i, int *gthr, hipStream_t st);
+                   float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect range = K1Collect{});
 // widening pass (COLLECT mode) over at most Q slots; defined in k1_collect.hip
 int k1_launch_collect(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N, int *gthr_slots,
                       K1Collect coll, hipStream_t st);

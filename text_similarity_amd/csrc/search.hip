@@ -122,32 +122,11 @@ struct GuardArgs {
     int *status;       // [Q] or null
 };
 
-// =====================================================================================================
-// K2: cos_topk_finalize — one wave per query.
-//   1. select the KL best of the P2*KL partial entries by (MFMA score desc, index asc);
-//   2. re-score them exactly (above);
-//   3. order by (exact score desc, index asc) and emit the first k;
-//   4. GUARD: every row outside the KL candidates has an MFMA score <= cut = the KL-th selected one, hence an exact
-//      score <= cut + eps when eps bounds |MFMA - exact| for the query.  eps is estimated from the candidates themselves
-//      (c1 x the largest difference observed, never below `floor`).  If cut + eps < the k-th exact score nothing outside
-//      can reach the list and the result stands; otherwise the query is FLAGGED: the widening pass (K1 in COLLECT mode)
-//      gathers every row whose MFMA score exceeds (k-th exact score - eps) and widen_finalize re-scores all of them.
-// =====================================================================================================
-template <int KL, typename T, bool COS>
-__global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__restrict__ part_s,
-                                                                const int *__restrict__ part_i, int P2,
-                                                                int64_t Q, int64_t N, const T *__restrict__ xq, int64_t ldq,
-                                                                const T *__restrict__ xc, int64_t ldc, int d, int k,
-                                                                float *__restrict__ out_s,
-                                                                int64_t *__restrict__ out_i,
-                                                                int64_t idx_offset, GuardArgs g) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= Q) return;
-    const int64_t E = (int64_t)P2 * KL;
-    const float *ps = part_s + q * E;
-    const int *pi = part_i + q * E;
-
+// The KL best entries of a query's partial lists by (MFMA score desc, index asc): lane t < KL returns the t-th
+// (my_i = -1 when there are fewer).  ps / pi: the query's lists, nlists of KL entries each, sorted, padded with (-inf, -1).
+template <int KL>
+__device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, const int *__restrict__ pi, int P2, int lane,
+                                               float &my_s_out, int &my_i_out) {
     // 1a. one pass: every lane keeps the KL best of its E/64 entries in a sorted register list
     float ls[KL];
     int li[KL];
@@ -190,7 +169,7 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
     }
 
     // 1b. KL rounds of a 64-way merge of the list heads; the winning lane pops its head
-    float my_s = -INFINITY;  // lane t < KL ends up holding the t-th selected candidate
+    float my_s = -INFINITY;
     int my_i = -1;
     for (int t = 0; t < KL; ++t) {
         float bs = ls[0];
@@ -219,6 +198,58 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
             li[KL - 1] = 0x7fffffff;
         }
     }
+    my_s_out = my_s;
+    my_i_out = my_i;
+}
+
+// Two-phase main pass: after the list kernel has scored the first rows of the shard (phase A: lists p2_first .. +p2_count of
+// every query), the KL-th best MFMA score found so far replaces the pre-pass bound in the query's shared threshold word.
+// Phase B then streams the rest of the shard against a bound taken from 4x more rows than the pre-pass sample: its
+// candidate events (the expensive, branchy side of the selection filter) fall accordingly.
+template <int KL>
+__global__ __launch_bounds__(256) void thr_update_kernel(const float *__restrict__ part_s, const int *__restrict__ part_i,
+                                                         int P2_total, int p2_first, int p2_count, int64_t Q,
+                                                         int *__restrict__ gthr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    float my_s;
+    int my_i;
+    select_kl_best<KL>(part_s + (q * P2_total + p2_first) * KL, part_i + (q * P2_total + p2_first) * KL, p2_count, lane, my_s, my_i);
+    const float kth = __shfl(my_s, KL - 1, 64);
+    const int kth_i = __shfl(my_i, KL - 1, 64);
+    if (lane == 0 && kth_i >= 0) atomicMax(gthr + q, float_to_ordered(kth));   // KL rows score at least kth
+}
+
+// =====================================================================================================
+// K2: cos_topk_finalize — one wave per query.
+//   1. select the KL best of the P2*KL partial entries by (MFMA score desc, index asc);
+//   2. re-score them exactly (above);
+//   3. order by (exact score desc, index asc) and emit the first k;
+//   4. GUARD: every row outside the KL candidates has an MFMA score <= cut = the KL-th selected one, hence an exact
+//      score <= cut + eps when eps bounds |MFMA - exact| for the query.  eps is estimated from the candidates themselves
+//      (c1 x the largest difference observed, never below `floor`).  If cut + eps < the k-th exact score nothing outside
+//      can reach the list and the result stands; otherwise the query is FLAGGED: the widening pass (K1 in COLLECT mode)
+//      gathers every row whose MFMA score exceeds (k-th exact score - eps) and widen_finalize re-scores all of them.
+// =====================================================================================================
+template <int KL, typename T, bool COS>
+__global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__restrict__ part_s,
+                                                                const int *__restrict__ part_i, int P2,
+                                                                int64_t Q, int64_t N, const T *__restrict__ xq, int64_t ldq,
+                                                                const T *__restrict__ xc, int64_t ldc, int d, int k,
+                                                                float *__restrict__ out_s,
+                                                                int64_t *__restrict__ out_i,
+                                                                int64_t idx_offset, GuardArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    const int64_t E = (int64_t)P2 * KL;
+    const float *ps = part_s + q * E;
+    const int *pi = part_i + q * E;
+
+    float my_s;  // lane t < KL ends up holding the t-th selected candidate
+    int my_i;
+    select_kl_best<KL>(ps, pi, P2, lane, my_s, my_i);
     const int nvalid = __popcll(__ballot(my_i >= 0));   // candidates sit in lanes 0 .. nvalid-1
 
     // 2. exact re-score: the wave works on one candidate at a time (coalesced row reads)
@@ -718,10 +749,17 @@ struct SearchWs {
 static void plan_workspace(int64_t Q, int64_t N, int k, SearchWs *w) {
     size_t part = 0;
     if (k <= TOPK_MAX_LISTS) {   // the plan depends on the padded width only through the wave count: take the larger layout
-        TopkPlan a, b;
-        plan_topk(Q, N, 384, k, &a);
-        plan_topk(Q, N, 768, k, &b);
-        part = a.part_elems > b.part_elems ? a.part_elems : b.part_elems;
+        for (int D : {384, 768}) {
+            TopkPlan a, pa, pb;
+            plan_topk(Q, N, D, k, &a);
+            size_t e = a.part_elems;
+            if (N >= 4 * 131072) {   // two-phase main pass: the lists of both launches side by side
+                plan_topk(Q, 131072, D, k, &pa);
+                plan_topk(Q, N - 131072, D, k, &pb);
+                if (pa.part_elems + pb.part_elems > e) e = pa.part_elems + pb.part_elems;
+            }
+            if (e > part) part = e;
+        }
     }
     int nch = (int)((N + 255) / 256);
     w->bf_nch = nch < 64 ? (nch < 1 ? 1 : nch) : 64;
@@ -785,6 +823,19 @@ static bool plan_fullmax(int64_t Q, int64_t N, int D, int kneed, TopkPlan *p) {
     return p->nchunks >= 8 && p->P2 >= kneed && p->P2 <= K1_PREPASS_MAX_P2 && N - (int64_t)(p->nchunks - 1) * rpc >= 8;
 }
 
+// Two-phase main pass (large shards): phase A = the first K1_PHASE_A_ROWS rows, phase B = the rest.
+constexpr int64_t K1_PHASE_A_ROWS = 131072;
+static bool plan_two_phase(int64_t Q, int64_t N, int D, int k, TopkPlan *pa, TopkPlan *pb) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("TSIM_K1_PHASES"); on = e ? atoi(e) : 1; }
+    // one or two query blocks: the chip is filled by corpus chunks alone and two extra launches cost more than the tighter
+    // bound saves (Q = 256: 0.37 -> 0.44 ms); from four query blocks on the second phase wins (Q = 4096: -3 %)
+    if (!on || N < 4 * K1_PHASE_A_ROWS || Q <= 768) return false;
+    plan_topk(Q, K1_PHASE_A_ROWS, D, k, pa);
+    plan_topk(Q, N - K1_PHASE_A_ROWS, D, k, pb);
+    return true;
+}
+
 static float guard_c1() {
     static float c1 = -1.f;
     if (c1 < 0.f) { const char *e = getenv("TSIM_GUARD_C1"); c1 = e ? (float)atof(e) : 4.0f; if (!(c1 >= 1.f)) c1 = 1.f; }
@@ -799,7 +850,7 @@ static int search_tail(const SearchWs &w, char *ws, int64_t Q, int64_t N, const 
     if (run_collect) {
         TopkPlan cp;
         plan_collect(Q, N, ld, &cp);
-        K1Collect coll;
+        K1Collect coll{};
         coll.qcount = g.ctl + CTL_NFLAG;
         coll.qmap = g.flag_q;
         coll.buf = reinterpret_cast<unsigned long long *>(ws + w.coll_buf);
@@ -903,9 +954,30 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
         hipEvent_t ev0 = g_ev_start, ev1 = g_ev_stop;
         g_ev_start = g_ev_stop = nullptr;
         if (ev0) TSIM_HIP_CHECK(hipEventRecord(ev0, st));
-        int rc = p.KL == 16 ? k1_launch_kl16(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st)
-                            : k1_launch_kl32(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st);
-        if (rc) return rc;
+        TopkPlan pa, pb;
+        if (plan_two_phase(Q, N, ld, k, &pa, &pb)) {
+            // main pass in two launches: rows [0, NA) with the pre-pass bounds, then the rest with the KL-th best score of
+            // phase A as the bound (thr_update_kernel).  Lists of both phases sit side by side: P2 = pa.P2 + pb.P2.
+            const int64_t NA = K1_PHASE_A_ROWS;
+            p.P2 = pa.P2 + pb.P2;
+            K1Collect ra{}, rb{};
+            ra.p2_base = 0; ra.p2_total = p.P2; ra.row_base = 0;
+            rb.p2_base = pa.P2; rb.p2_total = p.P2; rb.row_base = (int)NA;
+            int rc = p.KL == 16 ? k1_launch_kl16(pa, ld, uq, Q, uc, NA, part_s, part_i, gthr, st, ra)
+                                : k1_launch_kl32(pa, ld, uq, Q, uc, NA, part_s, part_i, gthr, st, ra);
+            if (rc) return rc;
+            const unsigned ug = (unsigned)((Q + 3) / 4);
+            if (p.KL == 16) hipLaunchKernelGGL(thr_update_kernel<16>, dim3(ug), dim3(256), 0, st, part_s, part_i, p.P2, 0, pa.P2, Q, gthr);
+            else hipLaunchKernelGGL(thr_update_kernel<32>, dim3(ug), dim3(256), 0, st, part_s, part_i, p.P2, 0, pa.P2, Q, gthr);
+            TSIM_HIP_CHECK(hipGetLastError());
+            rc = p.KL == 16 ? k1_launch_kl16(pb, ld, uq, Q, uc + NA * ld, N - NA, part_s, part_i, gthr, st, rb)
+                            : k1_launch_kl32(pb, ld, uq, Q, uc + NA * ld, N - NA, part_s, part_i, gthr, st, rb);
+            if (rc) return rc;
+        } else {
+            int rc = p.KL == 16 ? k1_launch_kl16(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st)
+                                : k1_launch_kl32(p, ld, uq, Q, uc, N, part_s, part_i, gthr, st);
+            if (rc) return rc;
+        }
         if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
         if (cosf) {
             if (p.KL == 16) launch_finalize<16, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k,

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import search_ref
+from conftest import golden
+from oracle import adjacent_ref, search_ref
 from text_similarity_amd import presets
 from text_similarity_amd.pipeline.clustering import ClusteringPipeline
 from text_similarity_amd.pipeline.ranking_pipeline import RankingPipeline
@@ -16,38 +17,54 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_retrieval_accuracy_meter_matches_dense_argmax():
+def test_retrieval_accuracy_meter_matches_reference_fixture():
+    """tests/golden/meters.npz: inputs and outputs of the REFERENCE's RetrievalAccuracyMeter (metrics.py:450-507)."""
+    g = golden("meters.npz")
+    n = g["src"].shape[0]
+    m = RetrievalAccuracyMeter(print_wrong_matches=True)
+    m.update(torch.from_numpy(g["src"]).to(DEV), torch.from_numpy(g["tgt"]).to(DEV), [f"s{i}" for i in range(n)],
+             [f"t{i}" for i in range(n)])
+    assert (m.src2tgt, m.tgt2src, m.avg) == (float(g["src2tgt"]), float(g["tgt2src"]), float(g["avg"]))
+    got_wrong = [[int(x) for x in ln.split(",")[0].replace("i:", "").replace("j:", "").split()] for ln in m.lines]
+    assert got_wrong == g["wrong_pairs"].tolist() and "INCORRECT" in str(m)
+    # a larger synthetic case against the numpy restatement (exact duplicates included: ties -> lower index)
     n, d = 700, 384
     src = presets.normal("n4/src", n * d).reshape(n, d)
     tgt = (src + 0.9 * presets.normal("n4/noise", n * d).reshape(n, d)).astype(np.float32)
-    tgt[5] = tgt[400]                                   # some wrong matches
-    m = RetrievalAccuracyMeter(print_wrong_matches=True)
-    m.update(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV), [f"s{i}" for i in range(n)], [f"t{i}" for i in range(n)])
-    # metrics.py:466-500 restated: dense cosine matrix (canonical scores of the same unit rows), argmax per row / column
-    sims = search_ref.canonical_scores(search_ref.unit_rows(src), search_ref.unit_rows(tgt))
-    s2t = float((sims.argmax(1) == np.arange(n)).mean())
-    t2s = float((sims.T.argmax(1) == np.arange(n)).mean())
-    assert m.src2tgt == pytest.approx(s2t, abs=1e-12) and m.tgt2src == pytest.approx(t2s, abs=1e-12)
-    assert m.avg == pytest.approx((s2t + t2s) / 2) and 0.5 < m.avg < 1.0
-    assert len(m.lines) == int(round((1 - s2t) * n)) and "INCORRECT" in str(m)
+    tgt[5] = tgt[400]
+    m2 = RetrievalAccuracyMeter(print_wrong_matches=False)
+    m2.update(torch.from_numpy(src).to(DEV), torch.from_numpy(tgt).to(DEV))
+    s2t, t2s, avg, _ = adjacent_ref.retrieval_accuracy(src, tgt)
+    assert (m2.src2tgt, m2.tgt2src) == (s2t, t2s) and 0.5 < m2.avg < 1.0
 
 
-def test_embedding_similarity_meter_matches_scipy():
-    from scipy.stats import pearsonr, spearmanr
-    n, d = 200, 64
-    a = presets.normal("n4/a", n * d).reshape(n, d)
-    b = (a + presets.normal("n4/b", n * d).reshape(n, d) * np.linspace(0.1, 3, n)[:, None]).astype(np.float32)
-    gold = np.linspace(5, 0, n)
+def test_embedding_similarity_meter_matches_reference_fixture():
+    """tests/golden/meters.npz: the reference's EmbeddingSimilarityMeter (metrics.py:317-381) — val / avg are its own
+    outputs, the eight correlations come from the scipy / sklearn calls it makes."""
+    g = golden("meters.npz")
     m = EmbeddingSimilarityMeter()
-    m.update((a, b), gold, n)
-    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
-    assert m.eval_pearson_cosine == pytest.approx(pearsonr(gold, cos)[0], abs=1e-5)
-    assert m.eval_spearman_euclidean == pytest.approx(spearmanr(gold, -np.linalg.norm(a - b, axis=1))[0], abs=1e-5)
-    assert m.val == pytest.approx(max(m.eval_spearman_cosine, m.eval_spearman_manhattan, m.eval_spearman_euclidean,
-                                      m.eval_spearman_dot)) and m.avg == m.val
+    m.update((g["sts_a"], g["sts_b"]), g["sts_gold"], len(g["sts_gold"]))
+    got = np.array([[getattr(m, f"eval_pearson_{k}"), getattr(m, f"eval_spearman_{k}")] for k in ("cosine", "manhattan", "euclidean", "dot")])
+    np.testing.assert_allclose(got, g["sts_corr"], rtol=0, atol=1e-5)
+    assert m.val == pytest.approx(float(g["sts_val"]), abs=1e-5) and m.avg == m.val
 
 
-def test_clustering_pipeline_recovers_separated_clusters():
+@pytest.mark.parametrize("case", ["separated", "overlap", "norms"])
+def test_clustering_pipeline_matches_sklearn_fixture(case):
+    """tests/golden/kmeans.npz: sklearn.cluster.KMeans (the reference's clusterer, clustering.py:14) from fixed initial
+    centres on RAW rows; 'norms' is the case where a cosine (spherical) assignment gives different labels."""
+    g = golden("kmeans.npz")
+    x, init = g[f"{case}_x"], g[f"{case}_init"]
+    pipe = ClusteringPipeline(init.shape[0], SimpleNamespace(device=DEV), None, init=init)
+    out = pipe(torch.from_numpy(x).to(DEV))
+    lab = pipe.labels_.cpu().numpy()
+    assert (lab == g[f"{case}_labels"]).mean() >= 0.999
+    np.testing.assert_allclose(pipe.cluster_centers_.cpu().numpy(), g[f"{case}_centers"], rtol=0, atol=5e-3)
+    assert abs(pipe.inertia_ - float(g[f"{case}_inertia"])) <= 1e-4 * float(g[f"{case}_inertia"])
+    assert sum(len(v) for v in out.values()) == x.shape[0]
+
+
+def test_clustering_pipeline_kmeanspp_recovers_separated_clusters():
     k, per, d = 7, 300, 384
     centers = presets.normal("n3/c", k * d).reshape(k, d) * 4
     x = (np.repeat(centers, per, 0) + presets.normal("n3/x", k * per * d).reshape(k * per, d)).astype(np.float32)
@@ -59,9 +76,8 @@ def test_clustering_pipeline_recovers_separated_clusters():
     lab = pipe.labels_.cpu().numpy()
     for c in range(k):                                   # every found cluster is one true cluster
         assert len(set(truth[perm][lab == c])) == 1
-    # assignment step == oracle top-1 against the final centres
-    _, ref = search_ref.cosine_topk(search_ref.unit_rows(x[perm]), search_ref.unit_rows(pipe.cluster_centers_.cpu().numpy()), 1)
-    np.testing.assert_array_equal(lab, ref[:, 0])
+    ref_lab, _, ref_inertia = adjacent_ref.kmeans_lloyd(x[perm], pipe.cluster_centers_.cpu().numpy(), max_iter=2)
+    np.testing.assert_array_equal(lab, ref_lab)          # a fixed point of the oracle's Lloyd step
 
 
 class _FakeModel:

@@ -200,3 +200,29 @@ def test_fp8_oracle_mx_blocks():
     q2, s2 = fp8_ref.mx_quantize(x * 4.0)
     np.testing.assert_array_equal(q2, q)
     np.testing.assert_array_equal(s2[x.reshape(5, 3, 32).any(-1)], s[x.reshape(5, 3, 32).any(-1)] + 2)
+
+
+# ---------------------------------------------------------------- adjacent callers (oracle/adjacent_ref.py, §8(f) N3 / N4)
+@pytest.mark.parametrize("case", ["separated", "overlap", "norms"])
+def test_kmeans_oracle_matches_sklearn_fixture(case):
+    from oracle import adjacent_ref
+    g = golden("kmeans.npz")
+    lab, c, inertia = adjacent_ref.kmeans_lloyd(g[f"{case}_x"], g[f"{case}_init"])
+    assert (lab == g[f"{case}_labels"]).mean() >= 0.999            # float32 (sklearn) vs float64 ties at cluster borders
+    np.testing.assert_allclose(c, g[f"{case}_centers"], rtol=0, atol=2e-3)
+    assert abs(inertia - float(g[f"{case}_inertia"])) <= 1e-4 * inertia
+    if case == "norms":   # the fixture where cosine assignment would NOT reproduce the reference
+        u = g["norms_x"] / np.linalg.norm(g["norms_x"], axis=1, keepdims=True)
+        cu = g["norms_centers"] / np.linalg.norm(g["norms_centers"], axis=1, keepdims=True)
+        assert ((u @ cu.T).argmax(1) != g["norms_labels"]).sum() >= 3
+
+
+def test_meter_oracles_match_reference_fixture():
+    from oracle import adjacent_ref
+    g = golden("meters.npz")
+    s2t, t2s, avg, wrong = adjacent_ref.retrieval_accuracy(g["src"], g["tgt"])
+    assert (s2t, t2s, avg) == (float(g["src2tgt"]), float(g["tgt2src"]), float(g["avg"]))
+    np.testing.assert_array_equal(wrong, g["wrong_pairs"])
+    corr, val = adjacent_ref.sts_correlations(g["sts_a"], g["sts_b"], g["sts_gold"])
+    np.testing.assert_allclose(corr, g["sts_corr"], rtol=0, atol=2e-6)
+    assert abs(val - float(g["sts_val"])) <= 2e-6 and float(g["sts_avg"]) == float(g["sts_val"])

@@ -45,9 +45,10 @@ def top1_matches(src_embeddings: torch.Tensor, tgt_embeddings: torch.Tensor):
     Ties go to the lower index, as numpy's argmax does."""
     d = src_embeddings.shape[1]
     dev = src_embeddings.device if src_embeddings.is_cuda else (tgt_embeddings.device if tgt_embeddings.is_cuda else torch.device("cuda"))
-    s = ops.l2norm_rows(src_embeddings.to(dev).float().contiguous())
-    t = ops.l2norm_rows(tgt_embeddings.to(dev).float().contiguous())
-    scores, idx = ops.cosine_topk(s, t, d, 1)
+    sf = src_embeddings.to(dev).float().contiguous()
+    tf = tgt_embeddings.to(dev).float().contiguous()
+    # scores and order are the float32 cosines the reference's cos_sim matrix holds (exact re-score of the MFMA candidates)
+    scores, idx = ops.cosine_topk(ops.l2norm_rows(sf), ops.l2norm_rows(tf), d, 1, eq_f32=sf, ec_f32=tf)
     return idx[:, 0], scores[:, 0]
 
 

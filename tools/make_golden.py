@@ -272,8 +272,66 @@ def g6_e2e():
          first_sentences=np.array(sents[:4]))
 
 
+# ------------------------------------------------------------------ G7 meters (§8(f) N4)
+def g7_meters():
+    """The reference's own RetrievalAccuracyMeter / EmbeddingSimilarityMeter (src/utils/metrics.py:317-381, 450-507)."""
+    import contextlib
+    import io
+    from src.utils.metrics import EmbeddingSimilarityMeter, RetrievalAccuracyMeter
+    n, d = 300, 96
+    src = presets.normal("g7/src", n * d).reshape(n, d).astype(np.float32)
+    tgt = (src * 1.7 + 1.1 * presets.normal("g7/noise", n * d).reshape(n, d)).astype(np.float32)
+    tgt[5] = tgt[200]
+    tgt[17] = tgt[16]          # exact duplicate rows: argmax ties resolve to the lower index
+    m = RetrievalAccuracyMeter(print_wrong_matches=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.update(torch.from_numpy(src), torch.from_numpy(tgt), [f"s{i}" for i in range(n)], [f"t{i}" for i in range(n)])
+    wrong = np.array([[int(x) for x in ln.split(",")[0].replace("i:", "").replace("j:", "").split()] for ln in m.lines], dtype=np.int64)
+    k, dd = 250, 64
+    a = presets.normal("g7/a", k * dd).reshape(k, dd).astype(np.float32)
+    b = (a + presets.normal("g7/b", k * dd).reshape(k, dd) * np.linspace(0.1, 3, k)[:, None]).astype(np.float32)
+    gold = np.linspace(5, 0, k).astype(np.float32)
+    e = EmbeddingSimilarityMeter()
+    e.update((a, b), gold, k)
+    # the reference never stores the eight correlations it computes (locals of update(), metrics.py:364-371): recompute them
+    # with the functions it calls, and keep its own outputs val / avg
+    from scipy.stats import pearsonr, spearmanr
+    from sklearn.metrics.pairwise import paired_cosine_distances, paired_euclidean_distances, paired_manhattan_distances
+    sims = {"cosine": 1 - paired_cosine_distances(a, b), "manhattan": -paired_manhattan_distances(a, b),
+            "euclidean": -paired_euclidean_distances(a, b), "dot": np.array([np.dot(x, y) for x, y in zip(a, b)])}
+    corr = np.array([[pearsonr(gold, sims[kk])[0], spearmanr(gold, sims[kk])[0]] for kk in ("cosine", "manhattan", "euclidean", "dot")])
+    save("meters.npz", src=src, tgt=tgt, src2tgt=np.float64(m.src2tgt), tgt2src=np.float64(m.tgt2src), avg=np.float64(m.avg),
+         wrong_pairs=wrong, sts_a=a, sts_b=b, sts_gold=gold, sts_val=np.float64(e.val), sts_avg=np.float64(e.avg),
+         sts_corr=corr)
+
+
+# ------------------------------------------------------------------ G8 k-means (§8(f) N3)
+def g8_kmeans():
+    """sklearn.cluster.KMeans, the class the reference's ClusteringPipeline instantiates (src/pipeline/clustering.py:2,14),
+    on RAW (un-normalised) rows.  The reference's default initialisation (k-means++ from sklearn's own RNG stream) cannot
+    be reproduced outside sklearn, so the fixture fixes the initial centres (init=array, n_init=1) and pins what Lloyd's
+    iterations make of them: labels, centres, inertia."""
+    from sklearn.cluster import KMeans
+    out = {}
+    rng = np.random.default_rng(77)
+    for name, k, per, d, spread, scale in (("separated", 7, 120, 64, 4.0, 1.0), ("overlap", 5, 200, 32, 1.2, 1.0),
+                                           ("norms", 6, 150, 48, 2.0, 6.0)):
+        centers = rng.standard_normal((k, d)).astype(np.float32) * spread
+        if name == "norms":    # clusters at very different distances from the origin: cosine and Euclidean assignment disagree
+            centers *= np.linspace(0.2, scale, k, dtype=np.float32)[:, None]
+        x = (np.repeat(centers, per, 0) + rng.standard_normal((k * per, d))).astype(np.float32)
+        x = x[rng.permutation(k * per)]
+        init = x[rng.choice(k * per, k, replace=False)].copy()
+        km = KMeans(n_clusters=k, init=init, n_init=1, max_iter=300, tol=0.0, algorithm="lloyd").fit(x)
+        out[f"{name}_x"], out[f"{name}_init"] = x, init
+        out[f"{name}_labels"], out[f"{name}_centers"] = km.labels_.astype(np.int64), km.cluster_centers_.astype(np.float32)
+        out[f"{name}_inertia"], out[f"{name}_n_iter"] = np.float64(km.inertia_), np.int64(km.n_iter_)
+    save("kmeans.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for g in which:
-        {"g1": g1_tiny, "g2": g2_presets, "g3": g3_pool, "g4": g4_cos, "g5": g5_topk, "g6": g6_e2e}[g]()
+        {"g1": g1_tiny, "g2": g2_presets, "g3": g3_pool, "g4": g4_cos, "g5": g5_topk, "g6": g6_e2e, "g7": g7_meters,
+         "g8": g8_kmeans}[g]()

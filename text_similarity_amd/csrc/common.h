@@ -154,10 +154,74 @@ __device__ __forceinline__ void gelu2(float &a, float &b) {
 #endif
 }
 
+// The same polynomial for N values at once as N INDEPENDENT scalar Horner chains, step by step: no instruction waits for
+// the one before it.  gelu2's packed chain is the cheaper form when issue slots are the limit (a VALU-bound epilogue:
+// 26 issue cycles per value), but a packed fp32 op beside MFMAs costs far more than its slot and every step waits for the
+// previous one (measured in ffn_fused_kernel: ~240 cycles per gelu2 call); where the values sit in the shadow of an MFMA
+// stream this form is the right one.  Bit-identical to gelu2 (same operations per value, fp32 fma).
+template <int N>
+__device__ __forceinline__ void gelu_n(float (&x)[N]) {
+#ifdef TSIM_GELU_ERF
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = gelu_erf(x[i]);
+#else
+    float xc[N], u[N], p[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        xc[i] = __builtin_amdgcn_fmed3f(x[i], -4.0f, 4.0f);
+        u[i] = xc[i] * xc[i];
+        p[i] = 9.56756410e-11f;
+    }
+    constexpr float c[8] = {-8.02642397e-09f, 3.00262883e-07f, -6.72069427e-06f, 1.02510894e-04f,
+                            -1.15122017e-03f, 9.92152281e-03f, -6.64609522e-02f, 3.98939520e-01f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = fmaf(p[i], u[i], c[k]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] * fmaf(xc[i], p[i], 0.5f);
+#endif
+}
+
+// gelu_n cut into 11 stages (0: clamp + square, 1..8: one Horner step each, 9: Phi, 10: x * Phi) so that a caller can place
+// one stage of N independent operations between the MFMAs of a dependent accumulation chain.  State: xc, u, p (N each).
+template <int ST, int N>
+__device__ __forceinline__ void gelu_stage(float (&x)[N], float (&xc)[N], float (&u)[N], float (&p)[N]) {
+    constexpr float c[8] = {-8.02642397e-09f, 3.00262883e-07f, -6.72069427e-06f, 1.02510894e-04f,
+                            -1.15122017e-03f, 9.92152281e-03f, -6.64609522e-02f, 3.98939520e-01f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if constexpr (ST == 0) {
+            xc[i] = __builtin_amdgcn_fmed3f(x[i], -4.0f, 4.0f);
+            u[i] = xc[i] * xc[i];
+            p[i] = 9.56756410e-11f;
+        } else if constexpr (ST <= 8) {
+            p[i] = fmaf(p[i], u[i], c[ST - 1]);
+        } else if constexpr (ST == 9) {
+            p[i] = fmaf(xc[i], p[i], 0.5f);
+        } else {
+            x[i] = x[i] * p[i];
+        }
+    }
+}
+
 // async global -> LDS copy of 16 bytes per lane; LDS destination = wave-uniform base + lane*16.
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+// ds_read_b128 at addr + immediate offset, and a COUNTED wait that names the register it releases (so that no use of it is
+// scheduled above the wait): the building blocks of hand-rolled LDS prefetch pipelines (hipcc's own schedule tends to wait
+// lgkmcnt(0) right behind the read it has just issued)
+typedef __attribute__((ext_vector_type(4))) uint32_t lds_u32x4;
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_imm(lds_u32x4 &dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_counted(lds_u32x4 &released) {   // all but the N youngest LDS operations are done
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(released) : "n"(N) : "memory");
 }
 
 template <int N>

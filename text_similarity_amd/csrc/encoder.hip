@@ -19,6 +19,9 @@
 
 #include <vector>
 
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "gemm_pp.h"
 
@@ -473,6 +476,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
     };
     [[maybe_unused]] unsigned long long xs_n = 0, xs_x = 0, xs_w = 0, xs_i = 0, xs_c = 0, xs_e = 0, xs_it = 0;   // (diagnostic build only)
+    // vmcnt bookkeeping across an epilogue: its NS global stores are YOUNGER than the two W tiles in flight, and vmcnt
+    // retires in issue order, so "all but my PPW youngest operations" (the plain ring wait) would drain every store of the
+    // epilogue before the next MFMA could start — for the next TWO steps (the tile waited for in step s was issued in step
+    // s-2).  Those two waits leave NS more operations outstanding instead.  Only when every store was issued for certain
+    // (all 64 lanes active: no exec-zero skip) — otherwise the plain, draining wait.
+    constexpr int NS = 12;   // global store instructions per wave and epilogue (both epilogue forms)
+    static_assert(BMX * 12 / (NW * 64) == 6, "store count of the staged epilogue");
+    int stores_younger = 0;
     issue(0, 0);
     issue(1, 1);
     for (int tt = 0; tt < total; ++tt) {
@@ -488,9 +499,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
             for (int s = 0; s < KSTEPS; ++s) bx[s] = *reinterpret_cast<const bf16x8 *>(xp + 16 * s);
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retire these ordinary loads here
+            stores_younger = 0;   // ... and with them (vmcnt(0)) everything older
         }
         const unsigned long long xt1 = XR_T();
-        wait_vmcnt<PPW>();
+#ifdef TSIM_XRES_DRAIN   // A/B: the plain ring wait everywhere (drains the epilogue's stores)
+        stores_younger = 0;
+#endif
+        if (stores_younger > 0) {
+            wait_vmcnt<PPW + NS>();
+            --stores_younger;
+        } else {
+            wait_vmcnt<PPW>();
+        }
         __builtin_amdgcn_s_barrier();
         const unsigned long long xt2 = XR_T();
         issue(tt + 2, (stage + 2) % XR_NSTAGE);
@@ -558,6 +578,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
                 }
+                if (m0 + 32 <= M) stores_younger = 2;   // wave-uniform: all 12 stores of this wave were issued
             } else {
                 // epilogue of output tile j: acc[i][q]: feature n0 + i*32 + (q&3) + 8*(q>>2) + 4*h, token m0 + r.
                 // A lane owns 32-byte pieces of 32 different token rows, so direct stores touch 32 cache lines per
@@ -622,12 +643,507 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
                     }
                     __builtin_amdgcn_s_barrier();   // image may be overwritten
                 }
+                if (mb0 + BMX <= M) stores_younger = 2;   // every thread issued its 12 stores
             }
             xs_e += XR_T() - xt4; xs_it += 1;
         }
     }
     wait_vmcnt<0>();
     XR_ACC(0, xs_n); XR_ACC(5, xs_x); XR_ACC(1, xs_w); XR_ACC(2, xs_i); XR_ACC(3, xs_c); XR_ACC(4, xs_e); XR_ACC(6, xs_it);
+}
+
+// =====================================================================================================
+// gemm_xres2: the register-resident K = 384 projection with the EPILOGUE OVERLAPPED.
+//
+// In gemm_xres_kernel every sixth tile-step all eight waves stop feeding the matrix pipe and run the epilogue of a
+// 192-feature item together (bias, GELU, packing, stores): 28 % of the kernel's time with the MFMA pipe idle, plus the
+// activation reloads (profiles/README.md).  Here an item is 96 features (three 32-feature sub-tiles, W tiles of 96 x 128 k:
+// the same 24 KiB per step, three steps per item) and there are TWO accumulator sets (2 x 48 VGPRs beside the 96 of the
+// resident activations): while the 24 MFMAs of a step accumulate item i, the wave finishes one sub-tile of item i-1 in
+// their shadow — two accumulator registers (GELU, bf16 pack) after every k-step, the half-wave swap and the two 16-byte
+// stores at the end of the step.  The bias is not added in the epilogue: the accumulators START from it.
+// Same k order per output as gemm_xres_kernel (ascending), so rows stay batch-invariant bit for bit.
+// =====================================================================================================
+constexpr int X2_BN = 96, X2_BK = 128, X2_NSTAGE = 3, X2_KG = 3, X2_NSUB = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
+                                                         const float *__restrict__ bias, bf16_t *__restrict__ out,
+                                                         int M, int N, int items_total) {
+    constexpr int K = 384, KSTEPS = K / 16, NW = 8, BMX = NW * 32;
+    constexpr int STAGE = X2_BN * X2_BK * 2;                 // 24 KiB
+    constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;  // 24 pieces, 3 per wave
+    static_assert(PIECES % NW == 0 && X2_KG * X2_BK == K, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ntiles = N / X2_BN;
+    const int it0 = (int)((int64_t)items_total * blockIdx.x / gridDim.x);
+    const int it1 = (int)((int64_t)items_total * (blockIdx.x + 1) / gridDim.x);
+    const int total = (it1 - it0) * X2_KG;                   // W tiles (steps) of this workgroup
+    if (total <= 0) return;
+
+    // LDS image of a W tile: 96 rows of 256 B (128 k), 16-byte slot c of row rr holds source chunk c ^ (rr & 15)
+    int src_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int sl = (wave * PPW + i) * 64 + lane;
+        const int row = sl >> 4, ch = (sl & 15) ^ (row & 15);
+        src_off[i] = row * K * 2 + ch * 16;
+    }
+    auto issue = [&](int st, int stage) __attribute__((always_inline)) {
+        const int s2 = st < total ? st : total - 1;           // past-the-end: re-read the last tile (uniform vmcnt)
+        const int j = (it0 + s2 / X2_KG) % ntiles, g = s2 % X2_KG;
+        const char *base = reinterpret_cast<const char *>(W) + ((int64_t)j * X2_BN * K + g * X2_BK) * 2;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            glds16(base + src_off[i], smem + stage * STAGE + (wave * PPW + i) * 1024);
+    };
+    // fragment of sub-tile i, k-step ks (of 8 in a tile): row i*32 + r, source chunk 2 ks + h -> slot (2 ks + h) ^ (r & 15)
+    int cks[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) cks[ks] = r * 256 + (((2 * ks + h) ^ (r & 15)) << 4);
+
+    // bias -> LDS once per workgroup (an ordinary global load inside the loop would drain the W ring at its first use)
+    const uint32_t bias_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + X2_NSTAGE * STAGE;
+    for (int p = wave; p * 256 < N; p += NW)
+        if (p * 256 + lane * 4 < N) glds16(bias + p * 256 + lane * 4, smem + X2_NSTAGE * STAGE + p * 1024);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    bf16x8 bx[KSTEPS];
+    int cur_mb = -1, m0 = 0;
+    f32x16 accA[X2_NSUB], accB[X2_NSUB];
+    int old_m0 = 0, old_n0 = 0;
+    int st = 0;                       // steps done: ring position
+    int young1 = 0, young2 = 0;       // global stores issued in the previous step / the one before (-1: unknown)
+
+    // epilogue of ONE finished sub-tile whose 16 registers have been packed into pk[8] (pk[2gq], pk[2gq+1] = the lane's four
+    // features 8gq + 4h .. +3 of group gq): swap half-waves so that every lane owns 8 contiguous features, two 16-byte stores
+    auto store_sub = [&](const uint32_t (&pk)[8], int mrow0, int ncol) __attribute__((always_inline)) -> int {
+        const int64_t m = mrow0 + r;
+        const bool full = mrow0 + 32 <= M;    // wave-uniform
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            uint32_t a0 = pk[2 * gq], a1 = pk[2 * gq + 1], b0 = pk[2 * gq + 2], b1 = pk[2 * gq + 3];
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            bf16_t *dst = out + m * N + ncol + 8 * gq + 8 * h;
+            if (full) *reinterpret_cast<uint4 *>(dst) = o;
+            else if (m < M) *reinterpret_cast<uint4 *>(dst) = o;
+        }
+        return full ? 2 : -1;
+    };
+    auto finish2 = [&](float y0, float y1) __attribute__((always_inline)) -> uint32_t {
+        if constexpr (EPI == EPI_GELU) gelu2(y0, y1);
+        return pack_bf16x2(y0, y1);
+    };
+
+    issue(0, 0);
+    issue(1, 1);
+    auto run_item = [&](f32x16 (&cur)[X2_NSUB], f32x16 (&old)[X2_NSUB], int item, auto with_old) __attribute__((always_inline)) {
+        constexpr bool OLD = decltype(with_old)::value;
+        if (item / ntiles != cur_mb) {                        // wave-uniform: new token block -> reload fragments
+            cur_mb = item / ntiles;
+            m0 = cur_mb * BMX + wave * 32;
+            const bf16_t *xp = X + (int64_t)(m0 + r) * K + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) bx[s] = *reinterpret_cast<const bf16x8 *>(xp + 16 * s);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retire these ordinary loads here
+            young1 = young2 = 0;                              // ... and with them (vmcnt(0)) everything older
+        }
+        const int n0 = (item % ntiles) * X2_BN;
+        // accumulators start from the bias: cur[i][q] belongs to feature n0 + 32 i + (q & 3) + 8 (q >> 2) + 4 h
+#pragma unroll
+        for (int i = 0; i < X2_NSUB; ++i) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bv[gq]) : "v"(bias_lds + (n0 + i * 32 + 4 * h + 8 * gq) * 4) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[i][q] = bv[q >> 2][q & 3];
+        }
+#pragma unroll
+        for (int g = 0; g < X2_KG; ++g) {
+            const int stage = st % X2_NSTAGE;
+            // ring wait: the tile of this step was issued two steps ago; the stores of the last two steps are younger than it
+            if (young1 == 0 && young2 == 0) wait_vmcnt<PPW>();
+            else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 2) wait_vmcnt<PPW + 2>();
+            else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 4) wait_vmcnt<PPW + 4>();
+            else wait_vmcnt<PPW>();                           // unknown store count: drain (always safe)
+            __builtin_amdgcn_s_barrier();
+            issue(st + 2, (stage + 2) % X2_NSTAGE);
+            const char *ws = smem + stage * STAGE;
+            uint32_t pk[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int i = 0; i < X2_NSUB; ++i) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 8192 + cks[ks]);
+                    cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bx[g * 8 + ks], cur[i], 0, 0, 0);
+                }
+                if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
+            }
+            young2 = young1;
+            young1 = 0;
+            if constexpr (OLD) young1 = store_sub(pk, old_m0, old_n0 + g * 32);
+            ++st;
+        }
+        old_m0 = m0;
+        old_n0 = n0;
+    };
+    int item = it0;
+    run_item(accA, accB, item++, std::false_type{});
+    for (; item + 2 <= it1; item += 2) {
+        run_item(accB, accA, item, std::true_type{});
+        run_item(accA, accB, item + 1, std::true_type{});
+    }
+    const bool lastA = item >= it1;          // the last finished item sits in accA, unless one more item goes into accB
+    if (!lastA) run_item(accB, accA, item, std::true_type{});
+    wait_vmcnt<0>();                         // no LDS-DMA may outlive the workgroup (past-the-end tiles)
+    // flush: the last item's three sub-tiles
+    auto flush = [&](f32x16 (&acc)[X2_NSUB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < X2_NSUB; ++g) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) pk[ks] = finish2(acc[g][2 * ks], acc[g][2 * ks + 1]);
+            (void)store_sub(pk, old_m0, old_n0 + g * 32);
+        }
+    };
+    if (lastA) flush(accA); else flush(accB);
+}
+
+// =====================================================================================================
+// ffn_fused: FFN1 -> GELU -> FFN2 -> +residual -> LayerNorm in ONE kernel (hidden 384; the [T, F] intermediate never leaves
+// the CU).  Unfused, a MiniLM layer writes and re-reads 412 MB of h = GELU(x W1^T + b1) through HBM: more traffic than all its
+// other tensors together, and the two projections around it sit at a third of the HBM roofline and a quarter of the MFMA
+// roofline at once (profiles/README.md).
+//
+// Workgroup = 128 tokens = 4 token groups of 32, TWO waves per group with different ROLES (partners w and w+4 share a SIMD):
+//   producer (waves 0-3): holds the group's x rows as MFMA B fragments (96 VGPRs); per phase s it scores ONE 32-feature chunk
+//          h^T[32 features x 32 tokens] = W1[chunk s] . x^T (24 MFMAs, accumulator starts from b1), applies GELU, rounds to
+//          bf16 and writes the tile to a 2-KiB LDS slot — in the accumulator's own layout, which IS the B-operand layout of
+//          the second product (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand");
+//          GELU + rounding of chunk s-1 run in the shadow of chunk s's MFMA chain (two accumulators);
+//   consumer (waves 4-7): holds the group's whole output row block y^T[384 features x 32 tokens] (12 accumulator tiles = 192
+//          VGPRs, starting from b2); per phase it adds chunk s-2: y^T[t] += W2[rows of t, chunk] . h (2 MFMAs per tile, 24).
+// The producer runs two chunks ahead of the consumer (two h slots per group), so on every SIMD one wave's GELU / LDS traffic
+// runs beside the other's MFMAs, and neither role needs more than ~230 registers: 96 + 192 in one wave would not fit.
+// The k order inside a k-step of the second product is the accumulator's row order (16 s + 8 (j >> 2) + 4 h + (j & 3)): W2 is
+// re-laid at load time (pack_ffn_w2_kernel) so that its A fragments are plain 16-byte reads.
+// W streams through a ring of five 24-KiB LDS slots by LDS-DMA, unit 2s = W1[chunk s], unit 2s+1 = W2[.., chunk s-2]: both
+// matrices are stored as the exact LDS images (pack_ffn_w*_kernel), so every DMA piece is 1 KiB of contiguous memory.  One
+// raw s_barrier per phase (it also publishes the h slot); phase s waits for its two units with vmcnt(3) (one younger unit
+// stays in flight) and issues units 2s+3, 2s+4.
+// Staging: 48 KiB per phase for 48 MFMAs per SIMD = 31 B/clk/CU at the full MFMA rate — the order of the measured L2 -> LDS
+// rates, so this kernel runs near the staging bound; what it removes is the HBM round trip of h.
+// Epilogue (consumers): residual added in the accumulator layout (16-byte loads + v_permlane32_swap, the store path
+// backwards), two-pass LayerNorm statistics inside the wave, 16-byte row stores.
+// Summation order per output: chunks ascending, the permuted k order inside: independent of what else is in the batch.
+// =====================================================================================================
+constexpr int FF_UNIT = 24576, FF_NSLOT = 5, FF_XB = 16384;   // ring unit, ring slots, h fragments (4 groups x 2 x 2 KiB)
+#ifdef TSIM_PP_STAMPS
+// DIAGNOSTIC build: [0..3] producer wave 0: phases, wait (vmcnt + barrier), DMA issue, work; [4..7] the same for consumer wave 4
+__device__ unsigned long long g_ff_stamps[8];
+#define FF_T() __builtin_amdgcn_s_memtime()
+#else
+#define FF_T() 0ull
+#endif
+template <int... I, class Fn>
+__device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, Fn &&f) {   // f(integral_constant<I>) for each I
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// W1 [F, 384] -> per 32-row chunk the K1-style LDS image: row rr, 16-byte slot c holds source chunk c ^ (rr & 15) (low 4 bits)
+__global__ __launch_bounds__(256) void pack_ffn_w1_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ img, int F) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte unit of the image
+    if (u >= (int64_t)F * 48) return;
+    const int c = (int)(u / 1536), sl = (int)(u % 1536);            // chunk, slot in the chunk image (32 rows x 48 slots)
+    const int rr = sl / 48, cc = sl % 48;
+    img[u] = W[((int64_t)(c * 32 + rr) * 48) + (cc ^ (rr & 15))];
+}
+// W2 [384, F] -> per 32-column chunk c: image [384 rows][4 slots of 16 B]; slot s' of row ro holds k-step s, half hh with
+// (2 s + hh) = s' ^ ((ro >> 2) & 3), its 8 elements in the accumulator's k order: W2[ro][32 c + 16 s + 8 (j >> 2) + 4 hh + (j & 3)]
+__global__ __launch_bounds__(256) void pack_ffn_w2_kernel(const bf16_t *__restrict__ W, bf16_t *__restrict__ img, int F) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // element of the image
+    if (e >= (int64_t)384 * F) return;
+    const int c = (int)(e / (384 * 32)), o = (int)(e % (384 * 32));
+    const int ro = o / 32, sp = (o % 32) / 8, j = o % 8;
+    const int sh = sp ^ ((ro >> 2) & 3), s = sh >> 1, hh = sh & 1;
+    img[e] = W[(int64_t)ro * F + 32 * c + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)];
+}
+
+__global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W1img,
+                                                        const bf16_t *__restrict__ W2img, const float *__restrict__ b1,
+                                                        const float *__restrict__ b2, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float eps, bf16_t *__restrict__ out,
+                                                        int M, int F) {
+    constexpr int K = 384, KSTEPS = 24, PPU = 3;             // pieces of a 24-KiB unit per wave (24 / 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tg = wave & 3, consumer = wave >> 2;
+    const int r = lane & 31, hh = lane >> 5;
+    const int nchunks = F / 32, nphases = nchunks + 2, nunits = 2 * nphases;
+    const int m0 = blockIdx.x * 128 + tg * 32;
+    char *ring = smem;
+    char *xbuf = smem + FF_NSLOT * FF_UNIT;                   // h fragments of (group, chunk parity): xbuf + (tg * 2 + par) * 2048
+    const uint32_t b1_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + FF_NSLOT * FF_UNIT + FF_XB;
+
+    // unit u of phase u/2: even = W1 image of chunk u/2 (producer); odd = W2 image of chunk u/2 - 2 (consumer, two phases behind)
+    auto issue_unit = [&](int u) __attribute__((always_inline)) {
+        const int uu = u < nunits ? u : nunits - 1;           // past-the-end: re-read the last unit (uniform vmcnt)
+        int c = (uu & 1) ? (uu >> 1) - 2 : (uu >> 1);
+        c = c < 0 ? 0 : (c >= nchunks ? nchunks - 1 : c);     // units outside the chunk range are never consumed: any valid source
+        const char *src = reinterpret_cast<const char *>((uu & 1) ? W2img : W1img) + (int64_t)c * FF_UNIT;
+        char *dst = ring + (uu % FF_NSLOT) * FF_UNIT;
+#ifdef TSIM_FF_DIAG_NODMA   // DIAGNOSTIC (results wrong): the kernel without its W stream
+        (void)src; (void)dst;
+#else
+#pragma unroll
+        for (int i = 0; i < PPU; ++i)
+            glds16(src + (wave * PPU + i) * 1024 + lane * 16, dst + (wave * PPU + i) * 1024);
+#endif
+    };
+    // b1 -> LDS (read per chunk inside the loop: an ordinary global load there would drain the ring)
+    for (int p = wave; p * 256 < F; p += 8)
+        if (p * 256 + lane * 4 < F) glds16(b1 + p * 256 + lane * 4, smem + FF_NSLOT * FF_UNIT + FF_XB + p * 1024);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    if (!consumer) {
+        // ================================================================ producer: FFN1 + GELU, one chunk per phase
+        bf16x8 bx[KSTEPS];   // B[k = 8 hh + j][col r] of k-step s = X[m0 + r][16 s + 8 hh + j]; rows past M repeat the last one
+        {
+            const int64_t row = m0 + r < M ? m0 + r : M - 1;
+            const bf16_t *xp = X + row * K + 8 * hh;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) bx[s] = *reinterpret_cast<const bf16x8 *>(xp + 16 * s);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retired before any LDS-DMA is in flight
+        }
+        issue_unit(0);
+        issue_unit(1);
+        issue_unit(2);
+        const int w1off = r * 768;                             // + (s >> 3) * 256 + (((2 (s & 7) + hh) ^ (r & 15)) << 4)
+        int w1x[8];
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) w1x[bb] = ((2 * bb + hh) ^ (r & 15)) << 4;
+        const uint32_t slot0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)xbuf) + tg * 4096 + lane * 32;
+        // Phase ph: the 24 MFMAs of chunk ph, and in their shadow GELU + bf16 of chunk ph-1 (whose accumulator was finished in
+        // the phase before) as sixteen independent polynomial chains (gelu_n): the accumulation chain of a chunk and the
+        // activation of the previous one overlap instead of following each other.  h of chunk c is published at the end of
+        // phase c+1 and read by the consumer in phase c+2.
+        f32x16 hprev;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) hprev[q] = 0.f;
+        [[maybe_unused]] unsigned long long fs_w = 0, fs_i = 0, fs_k = 0;
+        auto phase = [&](int ph, auto has_mfma, auto has_prev) __attribute__((always_inline)) {
+            constexpr bool MM = decltype(has_mfma)::value, PV = decltype(has_prev)::value;
+            [[maybe_unused]] const unsigned long long t0 = FF_T();
+            wait_vmcnt<PPU>();                                 // units 2ph, 2ph+1 landed (2ph+2 may be in flight)
+            __builtin_amdgcn_s_barrier();                      // ... for everyone; everyone is past phase ph-1
+            [[maybe_unused]] const unsigned long long t1 = FF_T();
+            issue_unit(2 * ph + 3);
+            issue_unit(2 * ph + 4);
+            [[maybe_unused]] const unsigned long long t2 = FF_T();
+            f32x16 hacc;
+            if constexpr (MM) {
+                f32x4 bv[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(bv[gq]) : "v"(b1_lds + (32 * ph + 8 * gq + 4 * hh) * 4) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
+#pragma unroll
+                for (int q = 0; q < 16; ++q) hacc[q] = bv[q >> 2][q & 3];
+            }
+            // the accumulation chain is ONE dependent MFMA after the other: fragment reads roll PF k-steps ahead (counted waits)
+            constexpr int PF = 6;
+            lds_u32x4 fr[PF + 1];
+            const uint32_t tb = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)(ring + ((2 * ph) % FF_NSLOT) * FF_UNIT)) + w1off;
+            auto rd = [&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                lds_read_b128_imm<(n >> 3) * 256>(fr[n % (PF + 1)], tb + w1x[n & 7]);
+            };
+            if constexpr (MM) ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
+            uint32_t hw[8];   // registers 8s .. 8s+7 of the finished tile, GELU'd and packed: the B fragment of k-step s
+            float gv[16], gxc[16], gu[16], gp[16];   // GELU of chunk ph-1 in 11 stages of 16 independent operations, one
+                                                     // stage behind every second MFMA of the chain (64 issue cycles per stage)
+            if constexpr (PV) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) gv[q] = hprev[q];
+            }
+            ff_static_for(std::make_integer_sequence<int, KSTEPS>{}, [&](auto sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (MM) {
+                    if constexpr (s + PF < KSTEPS) rd(std::integral_constant<int, s + PF>{});
+                    constexpr int younger = s + PF < KSTEPS ? PF : KSTEPS - 1 - s;
+                    lgkm_wait_counted<younger>(fr[s % (PF + 1)]);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[s % (PF + 1)]), bx[s], hacc, 0, 0, 0);
+                }
+                if constexpr (PV && (s & 1) && s / 2 <= 10) gelu_stage<s / 2, 16>(gv, gxc, gu, gp);
+                if constexpr (PV && s == 23) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hw[e] = pack_bf16x2(gv[2 * e], gv[2 * e + 1]);
+                }
+            });
+            if constexpr (PV) {
+                const u32x4 f0 = {hw[0], hw[1], hw[2], hw[3]}, f1 = {hw[4], hw[5], hw[6], hw[7]};
+                // slot of chunk ph-1's parity: its previous content (chunk ph-3) was read by the consumer in phase ph-1
+                asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                             ::"v"(slot0 + ((ph - 1) & 1) * 2048), "v"(f0), "v"(f1) : "memory");
+            }
+            if constexpr (MM) hprev = hacc;
+#ifdef TSIM_PP_STAMPS
+            { const unsigned long long t3 = FF_T(); fs_w += t1 - t0; fs_i += t2 - t1; fs_k += t3 - t2; }
+#endif
+        };
+        phase(0, std::true_type{}, std::false_type{});
+        for (int ph = 1; ph < nchunks; ++ph) phase(ph, std::true_type{}, std::true_type{});
+        phase(nchunks, std::false_type{}, std::true_type{});
+        phase(nchunks + 1, std::false_type{}, std::false_type{});      // the consumer's last phase: ring + barrier only
+        wait_vmcnt<0>();                                       // past-the-end units must not outlive the workgroup
+#ifdef TSIM_PP_STAMPS
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_ff_stamps[0], (unsigned long long)nphases); atomicAdd(&g_ff_stamps[1], fs_w);
+            atomicAdd(&g_ff_stamps[2], fs_i); atomicAdd(&g_ff_stamps[3], fs_k);
+        }
+#endif
+        return;
+    }
+    // ==================================================================== consumer: FFN2 into the whole row block
+    f32x16 y[12];    // y[t][q]: output feature 32 t + (q & 3) + 8 (q >> 2) + 4 hh of token m0 + r; starts from b2
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(b2 + 32 * t + 8 * gq + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[t][4 * gq + e] = bv[e];
+        }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(y[t]));   // retire the b2 loads before any LDS-DMA is in flight
+    issue_unit(0);
+    issue_unit(1);
+    issue_unit(2);
+    const int w2row = r * 64;                                  // + t * 2048 + (((2 s + hh) ^ ((r >> 2) & 3)) << 4)
+    const int w2x0 = ((0 + hh) ^ ((r >> 2) & 3)) << 4, w2x1 = ((2 + hh) ^ ((r >> 2) & 3)) << 4;
+    const char *hslot0 = xbuf + tg * 4096 + lane * 32;
+    [[maybe_unused]] unsigned long long cs_w = 0, cs_i = 0, cs_k = 0;
+    for (int ph = 0; ph < nphases; ++ph) {
+        [[maybe_unused]] const unsigned long long t0 = FF_T();
+        wait_vmcnt<PPU>();
+        __builtin_amdgcn_s_barrier();                          // units landed; the producer's h of chunk ph-2 is written
+        [[maybe_unused]] const unsigned long long t1 = FF_T();
+        issue_unit(2 * ph + 3);
+        issue_unit(2 * ph + 4);
+        [[maybe_unused]] const unsigned long long t2 = FF_T();
+        if (ph >= 2) {
+            const uint32_t hs = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)(hslot0 + ((ph - 2) & 1) * 2048));
+            lds_u32x4 hv0, hv1;
+            lds_read_b128_imm<0>(hv0, hs);
+            lds_read_b128_imm<16>(hv1, hs);
+            constexpr int PF = 4;
+            lds_u32x4 fr[PF + 1];
+            const uint32_t un = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)(ring + ((2 * ph + 1) % FF_NSLOT) * FF_UNIT)) + w2row;
+            const uint32_t ua0 = un + w2x0, ua1 = un + w2x1;
+            auto rd = [&](auto nc) __attribute__((always_inline)) {    // read n: tile n >> 1, k-step n & 1
+                constexpr int n = decltype(nc)::value;
+                lds_read_b128_imm<(n >> 1) * 2048>(fr[n % (PF + 1)], (n & 1) ? ua1 : ua0);
+            };
+            ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
+            lgkm_wait_counted<PF>(hv0);                        // the two h reads are older than the PF fragment reads
+            asm volatile("" : "+v"(hv1));
+            const bf16x8 h0 = __builtin_bit_cast(bf16x8, hv0), h1 = __builtin_bit_cast(bf16x8, hv1);
+            ff_static_for(std::make_integer_sequence<int, 24>{}, [&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                if constexpr (n + PF < 24) rd(std::integral_constant<int, n + PF>{});
+                constexpr int younger = n + PF < 24 ? PF : 23 - n;
+                lgkm_wait_counted<younger>(fr[n % (PF + 1)]);
+                y[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]), (n & 1) ? h1 : h0,
+                                                                   y[n >> 1], 0, 0, 0);
+            });
+        }
+#ifdef TSIM_PP_STAMPS
+        {
+#pragma unroll
+            for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(y[t]));
+            const unsigned long long t3 = FF_T();
+            cs_w += t1 - t0; cs_i += t2 - t1; cs_k += t3 - t2;
+        }
+#endif
+    }
+    wait_vmcnt<0>();
+#ifdef TSIM_PP_STAMPS
+    if (threadIdx.x == 256) {
+        atomicAdd(&g_ff_stamps[4], (unsigned long long)nphases); atomicAdd(&g_ff_stamps[5], cs_w);
+        atomicAdd(&g_ff_stamps[6], cs_i); atomicAdd(&g_ff_stamps[7], cs_k);
+    }
+#endif
+
+    // ---------------------------------------------------------------- epilogue: + residual, LayerNorm, store
+    const int64_t m = m0 + r;
+    const bool live = m < M;
+    const int64_t mr = live ? m : M - 1;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            // the lane's 16 bytes: the 8 features of group gq + hh; the swap turns them back into the accumulator layout
+            const uint4 o = *reinterpret_cast<const uint4 *>(X + mr * K + 32 * t + 8 * gq + 8 * hh);
+            auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+            const uint32_t a0 = s0[0], c0 = s0[1], a1 = s1[0], c1 = s1[1];
+            y[t][4 * gq + 0] += __uint_as_float(a0 << 16);
+            y[t][4 * gq + 1] += __uint_as_float(a0 & 0xffff0000u);
+            y[t][4 * gq + 2] += __uint_as_float(a1 << 16);
+            y[t][4 * gq + 3] += __uint_as_float(a1 & 0xffff0000u);
+            y[t][4 * gq + 4] += __uint_as_float(c0 << 16);
+            y[t][4 * gq + 5] += __uint_as_float(c0 & 0xffff0000u);
+            y[t][4 * gq + 6] += __uint_as_float(c1 << 16);
+            y[t][4 * gq + 7] += __uint_as_float(c1 & 0xffff0000u);
+        }
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s1 += y[t][q];
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / 384.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float dlt = y[t][q] - mean;
+            s2 = fmaf(dlt, dlt, s2);
+        }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = 1.0f / sqrtf(s2 * (1.0f / 384.0f) + eps);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * t + 8 * gq + 4 * hh;
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gamma + n), bv = *reinterpret_cast<const f32x4 *>(beta + n);
+            const float o0 = (y[t][4 * gq + 0] - mean) * rstd * gv[0] + bv[0], o1 = (y[t][4 * gq + 1] - mean) * rstd * gv[1] + bv[1];
+            const float o2 = (y[t][4 * gq + 2] - mean) * rstd * gv[2] + bv[2], o3 = (y[t][4 * gq + 3] - mean) * rstd * gv[3] + bv[3];
+            pk[2 * gq] = pack_bf16x2(o0, o1);
+            pk[2 * gq + 1] = pack_bf16x2(o2, o3);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gq], pk[2 * gq + 2], false, false);
+            auto s1w = __builtin_amdgcn_permlane32_swap(pk[2 * gq + 1], pk[2 * gq + 3], false, false);
+            if (live) *reinterpret_cast<uint4 *>(out + m * K + 32 * t + 8 * gq + 8 * hh) = make_uint4(s0[0], s1w[0], s0[1], s1w[1]);
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1002,8 +1518,48 @@ static int gemm_xres_nw(const bf16_t *X, const bf16_t *W, const float *bias, bf1
 }
 
 template <int EPI>
+static int gemm_xres2(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
+    constexpr int lds = X2_NSTAGE * X2_BN * X2_BK * 2 + 8192;   // ring | bias (N <= 2048)
+    if (N > 2048) return fail(TSIM_EUNSUPPORTED, "gemm_xres2: N=%d > 2048", N);
+    auto kern = gemm_xres2_kernel<EPI>;
+    static bool attr_done[64] = {};
+    int dev = 0;
+    TSIM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    const int items = ((M + 255) / 256) * (N / X2_BN);
+    const int grid = items < 256 ? items : 256;             // persistent workgroups, one per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, X, W, bias, out, M, N, items);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
+template <int EPI>
 static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
+    static int v2 = -1;
+    if (v2 < 0) { const char *e = getenv("TSIM_XRES2"); v2 = e ? atoi(e) : 1; }
+    if (v2 && N % X2_BN == 0) return gemm_xres2<EPI>(X, W, bias, out, M, N, st);
     return gemm_xres_nw<EPI, 8>(X, W, bias, out, M, N, st);   // 8 waves = 256 tokens per workgroup (4-wave groups measured slower)
+}
+
+static int ffn_fused(const bf16_t *X, const bf16_t *W1img, const bf16_t *W2img, const float *b1, const float *b2,
+                     const float *gamma, const float *beta, float eps, bf16_t *out, int M, int F, hipStream_t st) {
+    const int lds = FF_NSLOT * FF_UNIT + FF_XB + ((F * 4 + 1023) / 1024) * 1024;   // ring | h exchange | b1
+    if (lds > 160 * 1024) return fail(TSIM_EUNSUPPORTED, "ffn_fused: F=%d needs %d B of LDS", F, lds);
+    static bool attr_done[64] = {};
+    int dev = 0;
+    TSIM_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ffn_fused_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(ffn_fused_kernel, dim3((unsigned)((M + 127) / 128)), dim3(512), lds, st, X, W1img, W2img, b1, b2, gamma,
+                       beta, eps, out, M, F);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
 }
 
 template <int EPI>
@@ -1127,6 +1683,14 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
             if ((rc = repack(d.w1, F, H * 2, (void **)&d.p1))) return bail(rc);
             if ((rc = repack(d.w2, H, F * 2, (void **)&d.p2))) return bail(rc);
         }
+        if (!mx && H == 384 && F % 64 == 0 && F <= 4096) {   // fused FFN (ffn_fused_kernel): both matrices as LDS images
+            if ((rc = dev_alloc(e, (size_t)F * H * 2, (void **)&d.p1))) return bail(rc);
+            if ((rc = dev_alloc(e, (size_t)F * H * 2, (void **)&d.p2))) return bail(rc);
+            hipLaunchKernelGGL(pack_ffn_w1_kernel, dim3((unsigned)((F * 48 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.w1), reinterpret_cast<uint4 *>(d.p1), F);
+            hipLaunchKernelGGL(pack_ffn_w2_kernel, dim3((unsigned)((384 * F + 255) / 256)), dim3(256), 0, 0, d.w2, d.p2, F);
+            if (hipGetLastError() != hipSuccess) return bail(fail(TSIM_EHIP, "FFN weight packing failed"));
+        }
         std::vector<float> bq(3 * (size_t)H);
         memcpy(bq.data(), lw.bq, H * 4);
         memcpy(bq.data() + H, lw.bk, H * 4);
@@ -1191,6 +1755,11 @@ extern "C" int tsim_gemm_mxfp8(const void *xq, const void *xs, const void *wq, c
 }
 
 #ifdef TSIM_PP_STAMPS
+extern "C" int tsim_debug_ff_stamps(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsim::g_ff_stamps), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(tsim::g_ff_stamps), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
 extern "C" int tsim_debug_xr_stamps(unsigned long long *out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsim::g_xr_stamps), 64) != hipSuccess) return 1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(tsim::g_xr_stamps), z, 64) != hipSuccess) return 1; }
@@ -1266,8 +1835,17 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 continue;
             }
             if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
-            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, L.p1, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, L.p2, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
+            static int fused = -1;
+            // OFF by default: at the bench shape (67 k tokens = 525 blocks of 128 on 256 CUs: three rounds) the fused kernel
+            // takes 256 us per layer against 245 us for FFN1 + FFN2 + tail (profiles/README.md, round 2); kept for shapes that
+            // fill whole rounds and as the starting point of the next round
+            if (fused < 0) { const char *ev = getenv("TSIM_FFN_FUSED"); fused = ev ? atoi(ev) : 0; }
+            if (fused && H == 384 && L.p1 && L.p2) {
+                if ((rc = ffn_fused(e->x1, L.p1, L.p2, L.b1, L.b2, L.g2, L.be2, c.ln_eps, e->x0, T, F, st))) return rc;
+                continue;
+            }
+            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, nullptr, L.b1, e->h1, T, F, H, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

@@ -49,6 +49,21 @@ def pmc_per_kernel(directory: str, counter: str):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def pmc_main_pass_per_search(directory: str, counter: str, first: int):
+    """The counter of the first `first` main-pass launches, in dispatch order: the benchmark steps come first (two launches
+    per search: phase A, phase B); the Q = 256 probes bench.py runs afterwards (one launch each) are left out."""
+    f = newest(os.path.join(directory, "**", "*_counter_collection.csv"))
+    vals = []
+    with open(f, newline="") as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] == counter and MAIN_PASS in r["Kernel_Name"]:
+                vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+    return [v for _, v in sorted(vals)][:first]
+
+
+MAIN_PASS = "cos_topk_partial_kernelILi384ELi8ELi1ELi16ELb0ELb1ELb0ELb0E"   # (mangled: the half-precision signature does not demangle)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r01")
@@ -60,6 +75,9 @@ def main() -> None:
     ap.add_argument("--d", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cmd", default="python bench.py --steps 10 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--searches", type=int, default=4, help="searches (steps + warm-up) of the PMC command")
+    ap.add_argument("--launches-per-search", type=int, default=2,
+                    help="main-pass launches of one tsim_cosine_topk call (2 since round 2: phase A + phase B)")
     a = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     lines = [f"kernel stats: rocprofv3 --kernel-trace --stats -- {a.cmd}", ""]
@@ -80,18 +98,25 @@ def main() -> None:
         lines += ["", "PMC (separate passes, --pmc FETCH_SIZE / --pmc WRITE_SIZE, per launch averages; values in KiB as reported;",
                   "gfx950 correction per MI355X_MICROARCH.md HBM section: FETCH_SIZE x2 for wide coalesced reads)"]
         for name in fe:
-            if "tsim::" not in name:
+            if "tsim::" not in name and "4tsim" not in name:   # (half-precision signatures come out mangled: _ZN4tsim...)
                 continue
             f_kib, n = fe[name]
             w_kib = wr.get(name, (0.0, 0))[0]
             lines.append(f"  FETCH {f_kib:12.0f} KiB (x2 = {2 * f_kib * 1024 / 1e6:9.1f} MB)  WRITE {w_kib:10.0f} KiB "
                          f"({w_kib * 1024 / 1e6:8.1f} MB)  n={n}  {name[:90]}")
-            if "cos_topk_partial_kernel" in name and ", false, " in name.split("(")[0]:
+            if MAIN_PASS in name:      # the main pass (list kernel, PAIR schedule): per search = its launches of the step's grid
+                fv = pmc_main_pass_per_search(a.fetch, "FETCH_SIZE", a.searches * a.launches_per_search)
+                wv = pmc_main_pass_per_search(a.write, "WRITE_SIZE", a.searches * a.launches_per_search)
+                searches = len(fv) // a.launches_per_search
+                f_kib, w_kib = sum(fv) / max(searches, 1), sum(wv) / max(searches, 1)
+                lines.append(f"  main pass per search ({a.launches_per_search} launches, {searches} searches): FETCH x2 = "
+                             f"{2 * f_kib * 1024 / 1e6:.1f} MB, WRITE = {w_kib * 1024 / 1e6:.1f} MB")
                 traffic = {
                     "round": int(a.round.lstrip("r")), "gpu": "MI355X (gfx950)",
                     "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+                    "per": f"tsim_cosine_topk call = {a.launches_per_search} launches of this kernel (phase A rows [0, 131072), phase B the rest)",
                     "workload": {"queries_per_step": a.queries, "corpus_rows_per_gpu": a.rows, "d": a.d, "k": a.k},
-                    "kernel": name.split("(")[0].replace("void tsim::", "").replace(" ", ""),
+                    "kernel": "cos_topk_partial_kernel<384,8,1,16,MAXONLY=false,PAIR=true,COLLECT=false,PP=false>",
                     "fetch_size_kib": int(f_kib), "write_size_kib": int(w_kib),
                     "hbm_bytes_per_launch": int(2 * f_kib * 1024 + w_kib * 1024),
                     "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "

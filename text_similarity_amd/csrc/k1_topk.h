@@ -153,7 +153,15 @@ struct K1Collect {
 // Ring: three tile slots; tile t+2 is issued in L(t): its slot held tile t-1, last read in group 1's M(t-1), two barriers
 // earlier for either group.  Tile t+1 must have landed when group 0 starts M(t+1): group 0 waits for its pieces at the end
 // of L(t) (vmcnt(PPW): t+2 stays in flight), group 1 at the end of M(t) (vmcnt(0): it has not issued t+2 yet).
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false, bool PP = false>
+// M16 = the score tile is computed with v_mfma_f32_16x16x32_f16 (four 16x16 accumulators: query set qs x row set rs) instead
+// of one v_mfma_f32_32x32x16_f16: the same matrix-pipe time and the same LDS fragment traffic (one ds_read_b128 per two
+// instructions), but 9-10 % faster in this kernel (measured with the selection disabled: 2.72 -> 2.47 ms at Q = 4096; the
+// 16x16 shape draws less power per FLOP and the chip holds a higher clock, MI355X_MICROARCH.md).  In the 16x16 result layout a
+// lane holds TWO queries (lane&15 of each set) against 8 rows each; eight v_permlane32_swap per tile hand the upper half-wave's
+// set-0 values to the lower half-wave and the lower's set-1 values to the upper, after which every lane again owns ONE query
+// (set lane>>5, column lane&15) against 16 rows, in exactly the register -> row pattern of the 32x32 layout with the
+// row-half bit h = (lane>>4)&1.  Selection, queues, lists and the output format are unchanged.
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false, bool PP = false, bool M16 = false>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const unit_t *__restrict__ eq, int Q, const unit_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
@@ -173,7 +181,11 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 31, h = lane >> 5, x = r & 15;
+    static_assert(!M16 || (QW == 1 && KL <= 16 && !PP && D % 32 == 0), "16x16x32 form: one query set per wave, asm-pipelined tile loop");
+    // r = the wave's query this lane selects for, h = which half of the tile's 8-row groups it sees (its list = partition h
+    // of the chunk); c16 / g16 = column and k-group of the lane in the 16x16x32 operand layout
+    const int c16 = lane & 15, g16 = lane >> 4;
+    const int r = M16 ? c16 + 16 * (lane >> 5) : lane & 31, h = M16 ? (g16 & 1) : lane >> 5, x = lane & 15;
 
     // blockIdx -> (query block, corpus chunk).  Blocks b and b+8 share an XCD (round-robin dispatch), so
     // the nqb query blocks of one chunk are given the same b%8: they stream the same corpus rows at about
@@ -211,9 +223,23 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         const int qrow = (q0 + 32 * u + r < Q) ? (q0 + 32 * u + r) : (Q - 1);
         int qsrc = qrow;
         if constexpr (COLLECT) qsrc = wave_on ? coll.qmap[qrow] : 0;
-        const unit_t *qp = eq + (int64_t)qsrc * D + 8 * h;
+        if constexpr (M16) {
+            // B operand of 16x16x32, query set qs, k-step s (32 wide): column c16 = query q0 + 16 qs + c16, k = 32 s + 8 g16 + j.
+            // Every lane carries fragments of BOTH sets: bq[0][qs * KSTEPS/2 + s].  (qrow / thresholds: the lane's own query r.)
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const f16x8 *>(qp + 16 * s);
+            for (int qs = 0; qs < 2; ++qs) {
+                int qf = q0 + 16 * qs + c16;
+                qf = qf < Q ? qf : Q - 1;
+                if constexpr (COLLECT) qf = wave_on ? coll.qmap[qf] : 0;
+                const unit_t *qp = eq + (int64_t)qf * D + 8 * g16;
+#pragma unroll
+                for (int s = 0; s < KSTEPS / 2; ++s) bq[u][qs * (KSTEPS / 2) + s] = *reinterpret_cast<const f16x8 *>(qp + 32 * s);
+            }
+        } else {
+            const unit_t *qp = eq + (int64_t)qsrc * D + 8 * h;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) bq[u][s] = *reinterpret_cast<const f16x8 *>(qp + 16 * s);
+        }
         if constexpr (MAXONLY) {   // pre-pass: no thresholds (gthr is null)
             gt[u] = nullptr;
             thr[u] = -INFINITY;
@@ -222,6 +248,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             thr[u] = import_threshold(__hip_atomic_load(gt[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if constexpr (COLLECT)   // lanes past the last slot hold a copy of it: they must never queue anything
                 if (q0 + 32 * u + r >= Q) thr[u] = INFINITY;
+#ifdef TSIM_K1_NOSEL
+            thr[u] = INFINITY;   // TIMING-ONLY diagnostic: the filter runs but nothing ever passes it
+#endif
         }
     }
     // Make the compiler retire these ordinary loads HERE: inside the main loop only LDS-DMA is in flight
@@ -270,9 +299,12 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 
     // A-fragment read offsets: lane (r,h), k-step s reads chunk (2s+h) of row r -> slot (2s+h) ^ x.
     // (2s+h) ^ x = 16*(s>>3) + ((2*(s&7)+h) ^ x): eight base offsets + an immediate.
+    // 16x16x32: lane (c16, g16), row set rs, k-step s reads chunk 4s + g16 of row 16 rs + c16 -> slot (4s + g16) ^ c16
+    // = 16*(s>>2) + ((4*(s&3) + g16) ^ c16): four base offsets + an immediate (conflict-free in every ds_read_b128 lane group).
     int aoff[8];
 #pragma unroll
-    for (int bb = 0; bb < 8; ++bb) aoff[bb] = r * ROWB + (((2 * bb + h) ^ x) << 4);
+    for (int bb = 0; bb < 8; ++bb)
+        aoff[bb] = M16 ? c16 * ROWB + (((4 * (bb & 3) + g16) ^ c16) << 4) : (lane & 31) * ROWB + (((2 * bb + (lane >> 5)) ^ x) << 4);
 
     float ls[QW][KL];
     int li[QW][KL];
@@ -394,7 +426,47 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         for (int u = 0; u < QW; ++u)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[u][g] = 0.f;
-        if constexpr (QW == 1) {
+        if constexpr (M16) {
+            // 24 fragment reads per tile (k-step s = n>>1, row set rs = n&1), each feeding two 16x16x32 instructions (query sets 0
+            // and 1); reads roll PF ahead with counted lgkmcnt waits, as in the 32x32 form below.
+            constexpr int PF = 4;
+            constexpr int NRD = KSTEPS;   // (D/32) k-steps x 2 row sets
+            k1_u32x4 fr[PF + 1];
+            f32x4 a16[2][2];              // [query set][row set]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a16[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + stage * STAGE_BYTES;
+            auto rd = [&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                constexpr int ks = n >> 1, rs = n & 1;
+                k1_lds_read<(ks >> 2) * 256 + rs * 16 * ROWB>(fr[n % (PF + 1)], lbase + aoff[ks & 3]);
+            };
+            auto step = [&](auto sc) __attribute__((always_inline)) {
+                constexpr int n = decltype(sc)::value;
+                constexpr int ks = n >> 1, rs = n & 1;
+                if constexpr (n + PF < NRD) rd(std::integral_constant<int, n + PF>{});
+                constexpr int younger = n + PF < NRD ? PF : NRD - 1 - n;
+                k1_lgkm_wait<younger>(fr[n % (PF + 1)]);
+                a16[0][rs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[n % (PF + 1)]), bq[0][ks],
+                                                                     a16[0][rs], 0, 0, 0);
+                a16[1][rs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[n % (PF + 1)]),
+                                                                     bq[0][KSTEPS / 2 + ks], a16[1][rs], 0, 0, 0);
+            };
+            k1_static_for(std::make_integer_sequence<int, PF>{}, rd);
+            k1_static_for(std::make_integer_sequence<int, NRD>{}, step);
+            // a16[qs][rs][j] = query (16 qs + c16) x tile row (16 rs + 4 g16 + j).  Swap: lanes 0-31 keep their set-0 values and
+            // receive the set-0 values of lane+32 (rows 4 (g16+2) + j); lanes 32-63 receive the set-1 values of lane-32 (rows
+            // 4 (g16-2) + j) and keep their own.  For every lane the first result is then the 8m = 0 group and the second the
+            // 8m = 8 group of its query: acc[4 (2 rs + m) + j] = row 16 rs + 8 m + 4 h + j, the 32x32 layout.
+#pragma unroll
+            for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a16[0][rs][j]), __float_as_uint(a16[1][rs][j]), false, false);
+                    acc[0][8 * rs + j] = __uint_as_float(sw[0]);
+                    acc[0][8 * rs + 4 + j] = __uint_as_float(sw[1]);
+                }
+        } else if constexpr (QW == 1) {
             if constexpr (KL <= 16) {
                 // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step s, so an
                 // LDS read has PF MFMAs (PF*32 pipe cycles) to land.  Reads and waits are inline asm with COUNTED waits
@@ -711,12 +783,13 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     return 0;
 }
 
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false, bool PP = false>
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false, bool PP = false,
+          bool M16 = false>
 static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP>;
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP, M16>;
     // the > 64 KiB dynamic-LDS opt-in is per device (a process may drive several GPUs): set it once per device
     static bool attr_done[64] = {};
     int dev = 0;

@@ -99,7 +99,7 @@ if __name__ == "__main__":
     # --stamps: DIAGNOSTIC build of the ping-pong GEMM with in-kernel cycle stamps (tools/pp_stamps.py); rebuild without it after
     # -DNAME arguments are passed through to hipcc (A/B builds of compile-time variants; they force a rebuild)
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+    only = [f for a in sys.argv[1:] if a.startswith("--only=") for f in a.split("=", 1)[1].split(",")]
     build(force="--force" in sys.argv or "--stamps" in sys.argv or bool(defs),
           extra_flags=(["-DTSIM_PP_STAMPS"] if "--stamps" in sys.argv else []) + defs, only=only or None)
     print(LIB)

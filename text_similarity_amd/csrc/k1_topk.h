@@ -72,9 +72,9 @@ __device__ __forceinline__ float import_threshold(int key) {
     return ordered_to_float(key - 1);
 }
 
-template <int D, int NWAVES, int QW, bool PAIR = false>
+template <int D, int NWAVES, int QW, bool PAIR = false, int NST = K1_NSTAGE>
 constexpr int k1_lds_bytes() {
-    return (PAIR ? 4 : K1_NSTAGE) * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
+    return (PAIR ? 4 : NST) * K1_TILE_ROWS * D * 2 + NWAVES * QW * K1_QCAP * 64 * 8;
 }
 
 // Measured on MI355X (gpurun r01, N = 1 M, d = 384, k = 10; profiles/README.md):
@@ -161,7 +161,11 @@ struct K1Collect {
 // set-0 values to the lower half-wave and the lower's set-1 values to the upper, after which every lane again owns ONE query
 // (set lane>>5, column lane&15) against 16 rows, in exactly the register -> row pattern of the 32x32 layout with the
 // row-half bit h = (lane>>4)&1.  Selection, queues, lists and the output format are unchanged.
-template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false, bool PP = false, bool M16 = false>
+// NST = ring slots of the one-tile-per-barrier schedule (tiles t+1 .. t+NST-2 are in flight while tile t is scored).  Three
+// slots keep 48 KiB per CU in flight, which bounds a latency-limited stream (few query blocks: one 256-query block reaches
+// ~4.2 TB/s with the matrix pipe half idle); five slots double that.
+template <int D, int NWAVES, int QW, int KL, bool MAXONLY, bool PAIR, bool COLLECT = false, bool PP = false, bool M16 = false,
+          int NST = K1_NSTAGE>
 __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     const unit_t *__restrict__ eq, int Q, const unit_t *__restrict__ ec, int64_t N, int rows_per_chunk,
     int nchunks, int nqb, int *__restrict__ gthr, float *__restrict__ part_s,
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    static_assert(!M16 || (QW == 1 && KL <= 16 && !PP && D % 32 == 0), "16x16x32 form: one query set per wave, asm-pipelined tile loop");
+    static_assert(!M16 || (KL <= 16 && !PP && D % 32 == 0), "16x16x32 form: asm-pipelined tile loop");
     // r = the wave's query this lane selects for, h = which half of the tile's 8-row groups it sees (its list = partition h
     // of the chunk); c16 / g16 = column and k-group of the lane in the 16x16x32 operand layout
     const int c16 = lane & 15, g16 = lane >> 4;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
             // Every lane carries fragments of BOTH sets: bq[0][qs * KSTEPS/2 + s].  (qrow / thresholds: the lane's own query r.)
 #pragma unroll
             for (int qs = 0; qs < 2; ++qs) {
-                int qf = q0 + 16 * qs + c16;
+                int qf = q0 + 32 * u + 16 * qs + c16;
                 qf = qf < Q ? qf : Q - 1;
                 if constexpr (COLLECT) qf = wave_on ? coll.qmap[qf] : 0;
                 const unit_t *qp = eq + (int64_t)qf * D + 8 * g16;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
     // (s_waitcnt vmcnt(0)) before every ordinary LDS access that might alias it; the queues never overlap the
     // staging buffers.
     const uint32_t qaddr0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) +
-                            (PAIR ? 4 : K1_NSTAGE) * STAGE_BYTES + wave * (QW * K1_QCAP * 64 * 8) + lane * 8;
+                            (PAIR ? 4 : NST) * STAGE_BYTES + wave * (QW * K1_QCAP * 64 * 8) + lane * 8;
 
     auto drain = [&](auto uc) __attribute__((always_inline))  {
         constexpr int u = decltype(uc)::value;
@@ -417,6 +421,9 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 
     issue_tile(0, 0);
     issue_tile(1, 1);
+    if constexpr (!PAIR && !PP)
+#pragma unroll
+        for (int i = 2; i < NST - 1; ++i) issue_tile(i, i);
 
     auto compute_tile = [&](int t, int stage) __attribute__((always_inline))  {
         if (!wave_on) return;
@@ -427,14 +434,19 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[u][g] = 0.f;
         if constexpr (M16) {
-            // 24 fragment reads per tile (k-step s = n>>1, row set rs = n&1), each feeding two 16x16x32 instructions (query sets 0
-            // and 1); reads roll PF ahead with counted lgkmcnt waits, as in the 32x32 form below.
-            constexpr int PF = 4;
+            // 24 fragment reads per tile (k-step s = n>>1, row set rs = n&1), each feeding 2 QW 16x16x32 instructions (the wave's
+            // 2 QW query sets of 16); reads roll PF ahead with counted lgkmcnt waits, as in the 32x32 form below.  With QW = 2
+            // (four waves, one per SIMD) a wave owns the SIMD's matrix pipe: 8 independent accumulation chains, 4 instructions per
+            // fragment read.
+#ifndef TSIM_K1_PF16
+#define TSIM_K1_PF16 4
+#endif
+            constexpr int PF = TSIM_K1_PF16;
             constexpr int NRD = KSTEPS;   // (D/32) k-steps x 2 row sets
             k1_u32x4 fr[PF + 1];
-            f32x4 a16[2][2];              // [query set][row set]
+            f32x4 a16[2 * QW][2];         // [query set][row set]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a16[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4 * QW; ++i) a16[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
             const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + stage * STAGE_BYTES;
             auto rd = [&](auto nc) __attribute__((always_inline)) {
                 constexpr int n = decltype(nc)::value;
@@ -447,25 +459,29 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
                 if constexpr (n + PF < NRD) rd(std::integral_constant<int, n + PF>{});
                 constexpr int younger = n + PF < NRD ? PF : NRD - 1 - n;
                 k1_lgkm_wait<younger>(fr[n % (PF + 1)]);
-                a16[0][rs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[n % (PF + 1)]), bq[0][ks],
-                                                                     a16[0][rs], 0, 0, 0);
-                a16[1][rs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[n % (PF + 1)]),
-                                                                     bq[0][KSTEPS / 2 + ks], a16[1][rs], 0, 0, 0);
+#pragma unroll
+                for (int qs = 0; qs < 2 * QW; ++qs)
+                    a16[qs][rs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr[n % (PF + 1)]),
+                                                                          bq[qs >> 1][(qs & 1) * (KSTEPS / 2) + ks], a16[qs][rs], 0, 0, 0);
             };
             k1_static_for(std::make_integer_sequence<int, PF>{}, rd);
             k1_static_for(std::make_integer_sequence<int, NRD>{}, step);
-            // a16[qs][rs][j] = query (16 qs + c16) x tile row (16 rs + 4 g16 + j).  Swap: lanes 0-31 keep their set-0 values and
-            // receive the set-0 values of lane+32 (rows 4 (g16+2) + j); lanes 32-63 receive the set-1 values of lane-32 (rows
-            // 4 (g16-2) + j) and keep their own.  For every lane the first result is then the 8m = 0 group and the second the
-            // 8m = 8 group of its query: acc[4 (2 rs + m) + j] = row 16 rs + 8 m + 4 h + j, the 32x32 layout.
+            // a16[qs][rs][j] = query (16 qs + c16) x tile row (16 rs + 4 g16 + j).  Swap within each pair of sets: lanes 0-31 keep
+            // their even-set values and receive the even-set values of lane+32 (rows 4 (g16+2) + j); lanes 32-63 receive the
+            // odd-set values of lane-32 (rows 4 (g16-2) + j) and keep their own.  For every lane the first result is then the
+            // 8m = 0 group and the second the 8m = 8 group of its query: acc[4 (2 rs + m) + j] = row 16 rs + 8 m + 4 h + j, the
+            // 32x32 layout.
 #pragma unroll
-            for (int rs = 0; rs < 2; ++rs)
+            for (int u = 0; u < QW; ++u)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a16[0][rs][j]), __float_as_uint(a16[1][rs][j]), false, false);
-                    acc[0][8 * rs + j] = __uint_as_float(sw[0]);
-                    acc[0][8 * rs + 4 + j] = __uint_as_float(sw[1]);
-                }
+                for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a16[2 * u][rs][j]),
+                                                                   __float_as_uint(a16[2 * u + 1][rs][j]), false, false);
+                        acc[u][8 * rs + j] = __uint_as_float(sw[0]);
+                        acc[u][8 * rs + 4 + j] = __uint_as_float(sw[1]);
+                    }
         } else if constexpr (QW == 1) {
             if constexpr (KL <= 16) {
                 // rolling software pipeline: the fragment read of k-step s+PF is issued right before the MFMA of k-step s, so an
@@ -668,20 +684,21 @@ __global__ __launch_bounds__(NWAVES * 64) void cos_topk_partial_kernel(
         if (t < ntiles) do_pair(t, 0);
         if (t + 2 < ntiles) do_pair(t + 2, 2);
     } else {
+        static_assert(NST >= 3 && (NST - 2) * PPW <= 63, "ring depth");
         auto do_tile = [&](int t, int stage) __attribute__((always_inline))  {
-            wait_vmcnt<PPW>();                 // my pieces of tile t have landed (tile t+1 may be in flight)
+            wait_vmcnt<(NST - 2) * PPW>();     // my pieces of tile t have landed (tiles t+1 .. t+NST-2 may be in flight)
             __builtin_amdgcn_s_barrier();      // everyone's pieces landed; everyone is done reading tile t-1
-            issue_tile(t + 2, (stage + 2) % K1_NSTAGE);
+            issue_tile(t + NST - 1, (stage + NST - 1) % NST);   // into the slot of tile t-1
             compute_tile(t, stage);
         };
         int t = 0;
-        for (; t + 3 <= ntiles; t += 3) {
-            do_tile(t, 0);
-            do_tile(t + 1, 1);
-            do_tile(t + 2, 2);
-        }
-        if (t < ntiles) do_tile(t, 0);
-        if (t + 1 < ntiles) do_tile(t + 1, 1);
+        for (; t + NST <= ntiles; t += NST)
+            k1_static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) __attribute__((always_inline)) {
+                do_tile(t + decltype(sc)::value, decltype(sc)::value);
+            });
+        k1_static_for(std::make_integer_sequence<int, NST - 1>{}, [&](auto sc) __attribute__((always_inline)) {
+            if (t + decltype(sc)::value < ntiles) do_tile(t + decltype(sc)::value, decltype(sc)::value);
+        });
     }
     wait_vmcnt<0>();  // no LDS-DMA may outlive the workgroup
 #ifdef TSIM_PP_STAMPS
@@ -763,7 +780,12 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     p->nqb = (int)((Q + qpb - 1) / qpb);
     // enough workgroups to fill 256 CUs a few times over, but chunks as long as possible: the per-lane
     // selection cost falls with stream length (candidates ~ KL*ln(n/KL))
-    int64_t target = 512;
+    int64_t target = 256;   // one workgroup per CU (LDS allows one resident): 512 measured 3-9 % slower at Q <= 1024, equal at 4096
+    {   // A/B knob (profiles/README.md): workgroups the main pass aims for
+        static int env_target = -1;
+        if (env_target < 0) { const char *e = getenv("TSIM_K1_TARGET_WGS"); env_target = e ? atoi(e) : 0; }
+        if (env_target > 0) target = env_target;
+    }
     int64_t nch = (target + p->nqb - 1) / p->nqb;
     int64_t max_ch = (N + 255) / 256;  // at least 256 rows per chunk
     if (nch > max_ch) nch = max_ch;
@@ -784,12 +806,12 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
 }
 
 template <int D, int NWAVES, int QW, int KL, bool MAXONLY = false, bool PAIR = false, bool COLLECT = false, bool PP = false,
-          bool M16 = false>
+          bool M16 = false, int NST = K1_NSTAGE>
 static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                      float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
-    constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR>();
+    constexpr int lds = k1_lds_bytes<D, NWAVES, QW, PAIR, NST>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP, M16>;
+    auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP, M16, NST>;
     // the > 64 KiB dynamic-LDS opt-in is per device (a process may drive several GPUs): set it once per device
     static bool attr_done[64] = {};
     int dev = 0;

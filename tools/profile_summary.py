@@ -61,7 +61,7 @@ def pmc_main_pass_per_search(directory: str, counter: str, first: int):
     return [v for _, v in sorted(vals)][:first]
 
 
-MAIN_PASS = "cos_topk_partial_kernelILi384ELi8ELi1ELi16ELb0ELb1ELb0ELb0E"   # (mangled: the half-precision signature does not demangle)
+MAIN_PASS = "cos_topk_partial_kernelILi384ELi8ELi1ELi16ELb0ELb1ELb0ELb0ELb1ELi3E"   # (mangled: the half-precision signature does not demangle)
 
 
 def main() -> None:
@@ -116,7 +116,7 @@ def main() -> None:
                     "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline",
                     "per": f"tsim_cosine_topk call = {a.launches_per_search} launches of this kernel (phase A rows [0, 131072), phase B the rest)",
                     "workload": {"queries_per_step": a.queries, "corpus_rows_per_gpu": a.rows, "d": a.d, "k": a.k},
-                    "kernel": "cos_topk_partial_kernel<384,8,1,16,MAXONLY=false,PAIR=true,COLLECT=false,PP=false>",
+                    "kernel": "cos_topk_partial_kernel<384,8,1,16,MAXONLY=false,PAIR=true,COLLECT=false,PP=false,M16=true,NST=3>",
                     "fetch_size_kib": int(f_kib), "write_size_kib": int(w_kib),
                     "hbm_bytes_per_launch": int(2 * f_kib * 1024 + w_kib * 1024),
                     "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md "

@@ -230,4 +230,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may drive several GPUs), so each
+// call site keeps one flag per device: `static DevOnce once; TSIM_MAX_LDS(once, kern, bytes);`
+struct DevOnce { bool done[64] = {}; };
+#define TSIM_MAX_LDS(once, kern, bytes)                                                                              \
+    do {                                                                                                             \
+        int dev_ = 0;                                                                                                \
+        TSIM_HIP_CHECK(hipGetDevice(&dev_));                                                                         \
+        if (dev_ < 0 || dev_ >= 64 || !(once).done[dev_]) {                                                          \
+            TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)));                \
+            if (dev_ >= 0 && dev_ < 64) (once).done[dev_] = true;                                                    \
+        }                                                                                                            \
+    } while (0)
+
 }  // namespace tsim

@@ -641,12 +641,8 @@ static int launch_pp(const void *X, const void *W, const uint8_t *xs, const uint
     constexpr int lds = 2 * (PP_XB + BN * 128 + (MX ? PP_SCALES : 0));   // the epilogue stages through the idle slot
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_pp_kernel<EPI, KSEC, MX, BN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_done = true;
-    }
+    static DevOnce lds_once;
+    TSIM_MAX_LDS(lds_once, kern, lds);
     const int mtiles = (M + PP_BM - 1) / PP_BM, ntiles = N / BN;
     const int total = ((mtiles + 7) / 8) * 8 * ntiles;
     static int persist = -1;

@@ -813,14 +813,8 @@ static int launch_k1(const TopkPlan &p, const unit_t *eq, int64_t Q, const unit_
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = cos_topk_partial_kernel<D, NWAVES, QW, KL, MAXONLY, PAIR, COLLECT, PP, M16, NST>;
     // the > 64 KiB dynamic-LDS opt-in is per device (a process may drive several GPUs): set it once per device
-    static bool attr_done[64] = {};
-    int dev = 0;
-    TSIM_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-        TSIM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if (dev >= 0 && dev < 64) attr_done[dev] = true;
-    }
+    static DevOnce lds_once;
+    TSIM_MAX_LDS(lds_once, kern, lds);
     const int grid = p.nchunks >= 8 ? ((p.nchunks + 7) / 8) * 8 * p.nqb
                                     : 8 * ((p.nqb + (8 / p.nchunks) - 1) / (8 / p.nchunks));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWAVES * 64), lds, st, eq, (int)Q, ec, N, p.rows_per_chunk,

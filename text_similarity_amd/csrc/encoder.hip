@@ -1577,15 +1577,20 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
             static int split = -1;
             if (split < 0) { const char *e = getenv("TSIM_LN_TAIL"); split = e ? atoi(e) : 1; }
             const int mt = (M + 127) / 128, full = (mt / 256) * 256, rem = mt - full;
+            // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep
+            // path issues a k-tile's DMA pieces in one burst ahead of the MFMAs instead of behind each k-step's)
+            auto main_launch = [&](int rows) {
+                return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st);
+            };
             if (split && full > 0 && rem > 0 && rem <= 96) {
                 const int m_main = full * 128;
-                int rc = launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, m_main, N, K, st);
+                int rc = main_launch(m_main);
                 if (rc) return rc;
                 // (a three-slot ring for the remainder launch measured no different: 2.744-2.751 vs 2.751-2.752 ms per forward)
                 return launch_gemm<32, 384, 64, 1, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
                                                                   gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st);
             }
-            return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
+            return main_launch(M);
         }
         case 768: return launch_gemm<64, 768, 32, 1, 8, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);
         case 64: return launch_gemm<128, 64, 64, 4, 2, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, M, N, K, st);

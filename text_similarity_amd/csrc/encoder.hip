@@ -1301,38 +1301,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
 }
 
 // =====================================================================================================
-// masked mean-pool over the packed layout (A4) + optional fused L2-normalise to bf16 (search operand).
+// masked mean-pool over the packed layout (A4) + optional fused L2-normalise to half precision (search operand).
 // One wave per sequence: pooled[b] = sum_t x[t] / max(len, 1e-9).  HBM-bound: T*H*2 B in.
+// A lane owns 16-byte pieces of the row (features 8c .. 8c+7 for c = lane, lane + 64): one 16-byte load per token and
+// piece (the first form read 2 bytes per lane and load: 48 us for 52 MB).  Per feature the sum still runs over the
+// tokens in ascending order in float32, and the squared norm is taken in the canonical element order of
+// tsim_l2norm_rows (element j on lane j % 64, ascending, then the xor butterfly) from a wave-private LDS copy of the
+// pooled row, so pooled and unit rows keep their bits.
 // =====================================================================================================
-template <int VPL>
+template <int NP>   // 16-byte pieces per lane = ceil(H / 512)
 __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restrict__ x,
                                                           const int32_t *__restrict__ cu, int B, int H,
                                                           float *__restrict__ pooled, unit_t *__restrict__ unit,
                                                           int ld_unit) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float rows[4][NP * 512];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
     if (b >= B) return;
     const int t0 = cu[b], t1 = cu[b + 1];
-    float s[VPL];
+    float s[NP][8];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) s[i] = 0.f;
-    for (int t = t0; t < t1; ++t) {
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) s[i] += bf16_to_f32(x[(int64_t)t * H + lane + i * 64]);
+        for (int e = 0; e < 8; ++e) s[p][e] = 0.f;
+    // the loop is latency-bound (one dependent-free load per token): four tokens' loads are issued together, the adds stay in
+    // token order
+    auto add_row = [&](int p, const uint4 &v) __attribute__((always_inline)) {
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[p][2 * q] += __uint_as_float(wv[q] << 16);
+            s[p][2 * q + 1] += __uint_as_float(wv[q] & 0xffff0000u);
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int f0 = (lane + 64 * p) * 8;
+        if (f0 >= H) continue;
+        const bf16_t *xp = x + f0;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4 *>(xp + (int64_t)(t + u) * H);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add_row(p, v[u]);
+        }
+        for (; t < t1; ++t) add_row(p, *reinterpret_cast<const uint4 *>(xp + (int64_t)t * H));
     }
     const float den = fmaxf((float)(t1 - t0), 1e-9f);
-    double ss = 0.0;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        s[i] = s[i] / den;
-        ss = fma((double)s[i], (double)s[i], ss);
-        if (pooled) pooled[(int64_t)b * H + lane + i * 64] = s[i];
+    for (int p = 0; p < NP; ++p) {
+        const int f0 = (lane + 64 * p) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[p][e] = s[p][e] / den;
+        if (f0 < H) {
+            const float4 lo = make_float4(s[p][0], s[p][1], s[p][2], s[p][3]), hi = make_float4(s[p][4], s[p][5], s[p][6], s[p][7]);
+            if (pooled) {
+                *reinterpret_cast<float4 *>(pooled + (int64_t)b * H + f0) = lo;
+                *reinterpret_cast<float4 *>(pooled + (int64_t)b * H + f0 + 4) = hi;
+            }
+            *reinterpret_cast<float4 *>(&rows[w][f0]) = lo;
+            *reinterpret_cast<float4 *>(&rows[w][f0 + 4]) = hi;
+        }
     }
     if (unit) {  // identical bits to tsim_l2norm_rows(pooled): same element order, same float64 scale
+        __builtin_amdgcn_wave_barrier();   // wave-private row: LDS operations of one wave execute in order
+        double ss = 0.0;
+        for (int jx = lane; jx < H; jx += 64) {
+            const float v = rows[w][jx];
+            ss = fma((double)v, (double)v, ss);
+        }
         const double inv = canonical_inv_norm(ss, 1e-8f);
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) unit[(int64_t)b * ld_unit + lane + i * 64] = canonical_unit_elem(s[i], inv);
-        for (int j = H + lane; j < ld_unit; j += 64) unit[(int64_t)b * ld_unit + j] = 0;
+        for (int p = 0; p < NP; ++p) {
+            const int f0 = (lane + 64 * p) * 8;
+            if (f0 < H) {
+                f16x8 u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) u[e] = canonical_unit_elem(s[p][e], inv);
+                *reinterpret_cast<f16x8 *>(unit + (int64_t)b * ld_unit + f0) = u;
+            }
+        }
+        for (int jx = H + lane; jx < ld_unit; jx += 64) unit[(int64_t)b * ld_unit + jx] = 0;
     }
 }
 
@@ -1840,7 +1891,11 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     if (pooled_f32 || unit_bf16) {
         const unsigned g = (unsigned)((B + 3) / 4);
 #define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (unit_t *)unit_bf16, ld_unit)
-        if (H == 64) POOL(1); else if (H == 384) POOL(6); else POOL(12);
+        if (H % 8 != 0 || H > 1024 || (unit_bf16 && ld_unit % 8 != 0))
+            return fail(TSIM_EUNSUPPORTED, "encoder: pooling needs a hidden size that is a multiple of 8, at most 1024 (got %d)", H);
+        if (((uintptr_t)pooled_f32 | (uintptr_t)unit_bf16) & 15)
+            return fail(TSIM_EINVAL, "encoder: pooled / unit outputs must be 16-byte aligned");
+        if (H <= 512) POOL(1); else POOL(2);
 #undef POOL
         TSIM_HIP_CHECK(hipGetLastError());
     }

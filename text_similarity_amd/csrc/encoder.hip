@@ -1200,13 +1200,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
         f32x16 sc;
 #pragma unroll
         for (int g = 0; g < 16; ++g) sc[g] = 0.f;
+        // the key block's V rows are requested together with its K rows (measured equal to requesting them after the softmax)
+        constexpr int CH = DH / 16;                          // 16-byte chunks per half row of V
+        uint4 vr[CH];
         {
             const bf16_t *kp = qkv + tk * H3 + H + head * DH + 8 * h;
+            const bf16_t *vsrc = qkv + tk * H3 + 2 * H + head * DH + h * (DH / 2);
+            bf16x8 kf[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + 16 * s);
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sc, 0, 0, 0);
-            }
+            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * s);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) vr[c] = *reinterpret_cast<const uint4 *>(vsrc + 8 * c);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
         }
         // sc[g]: key k0 + (g&3) + 8(g>>2) + 4h, query qi
         float bm = -INFINITY;
@@ -1251,11 +1257,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
         // (16 load instructions per k-step pair) were the kernel's largest cost.  EXEC is full here (out-of-range keys and
         // queries are clamped, not masked), as the instruction requires.
         {
-            constexpr int CH = DH / 16;                      // 16-byte chunks per half row
-            const bf16_t *vsrc = qkv + tk * H3 + 2 * H + head * DH + h * (DH / 2);
-            uint4 vr[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) vr[c] = *reinterpret_cast<const uint4 *>(vsrc + 8 * c);
             char *vrow = vimg + wave * (32 * ROWB) + r * ROWB + h * DH;
 #pragma unroll
             for (int c = 0; c < CH; ++c) *reinterpret_cast<uint4 *>(vrow + 16 * c) = vr[c];

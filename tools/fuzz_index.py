@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised sequences of add / delete / search / save+load on GpuFlatIndex against a plain Python model of the same
-index (live rows in insertion order + the oracle's exact top-k).  Usage: python tools/fuzz_index.py [rounds] [seed]"""
+index (live rows in insertion order + the oracle's exact top-k of the reference's float32 cosine).  Usage: python tools/fuzz_index.py [rounds] [seed]"""
 import sys, os, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -50,7 +50,7 @@ for rd in range(rounds):
             else:
                 live, ll = np.stack(rows), np.asarray(labels)
                 kk = min(k, len(rows))
-                rs, ri = search_ref.cosine_topk(search_ref.unit_rows(q), search_ref.unit_rows(live), kk)
+                rs, ri = search_ref.cosine_topk_f32(q, live, kk)      # the index keeps the float32 rows: the reference's cosine
                 ok = np.array_equal(lab[:, :kk], ll[ri]) and np.array_equal(sc[:, :kk], rs) and (lab[:, kk:] == -1).all()
             ok = ok and idx.num_live() == len(rows)
             bad += not ok

@@ -42,7 +42,14 @@ for c in range(cases):
     m3 = (mask.astype(bool) & rows_ok[:, None])
     eh = float(np.abs(hid - rh)[m3].max()) if m3.any() else 0.0
     ep = float(np.abs(pooled - rp)[rows_ok].max()) if rows_ok.any() else 0.0
-    ok = np.isfinite(hid).all() and eh <= 8e-2 and ep <= 5e-2 and (hid[mask == 0] == 0).all() and (pooled[~rows_ok] == 0).all()
+    # a pooled row is an average of hidden rows, so its error is bounded by theirs (a one-token row IS its hidden row: the old
+    # 5e-2 pooled bound was tighter than the 8e-2 hidden bound and tripped on such a row of the 12-layer model); the pooling itself
+    # is checked tightly against the mean of the kernel's own hidden states
+    den = np.maximum(mask.sum(1, keepdims=True), 1e-9)
+    self_pool = (hid.astype(np.float64) * mask[:, :, None]).sum(1) / den
+    es = float(np.abs(pooled - self_pool).max())
+    ok = (np.isfinite(hid).all() and eh <= 8e-2 and ep <= 8e-2 and es <= 1e-5 and (hid[mask == 0] == 0).all()
+          and (pooled[~rows_ok] == 0).all())
     bad += not ok
     print(f"case {c:2d} {preset:18s} B={B} S={S:2d} hidden err={eh:.4f} pooled err={ep:.4f} {'ok' if ok else 'MISMATCH'}", flush=True)
 print(f"fuzz_padded: {cases - bad}/{cases} ok")

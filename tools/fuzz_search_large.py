@@ -48,6 +48,11 @@ for c in range(cases):
     # sortedness / validity of every list
     sv, iv = s.cpu().numpy(), i.cpu().numpy()
     ok = ok and bool((np.diff(sv, axis=1) <= 0).all()) and bool(((iv >= 0) & (iv < N)).all())
+    # the reference's definition (float32 rows, exact re-score + guard)
+    s2, i2 = ops.cosine_topk(eq, ec, d, k, eq_f32=q, ec_f32=x)
+    torch.cuda.synchronize()
+    fs, fi = search_ref.cosine_topk_f32(q.cpu().numpy()[qs], x.cpu().numpy(), k)
+    ok = ok and np.array_equal(i2.cpu().numpy()[qs], fi) and np.array_equal(s2.cpu().numpy()[qs], fs)
     bad += not ok
     print(f"case {c:3d} d={d:3d} Q={Q:4d} N={N:7d} k={k:2d} {kind:7s} {'ok' if ok else 'MISMATCH'}  ({time.time() - t0:.0f} s)", flush=True)
     del x, q, eq, ec

@@ -832,16 +832,17 @@ template <int KL, bool MAXONLY = false, bool COLLECT = false>
 static int launch_k1_kl(const TopkPlan &p, int D, const unit_t *eq, int64_t Q, const unit_t *ec, int64_t N,
                         float *part_s, int *part_i, int *gthr, hipStream_t st, K1Collect coll = K1Collect{}) {
     constexpr bool M = KL <= 16;   // the 16x16x32 form wherever the asm-pipelined tile loop is used (lists of 16, pre-pass, collect)
+    constexpr bool P = KL <= 16 && !MAXONLY && !COLLECT;   // two tiles per barrier for the list-of-16 main pass (as at D = 384)
     switch (D) {
-        case 128: return launch_k1<128, 8, 1, KL, MAXONLY, false, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
-        case 256: return launch_k1<256, 8, 1, KL, MAXONLY, false, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+        case 128: return launch_k1<128, 8, 1, KL, MAXONLY, P, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+        case 256: return launch_k1<256, 8, 1, KL, MAXONLY, P, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 384: {
             if constexpr (!MAXONLY && !COLLECT && KL == 16)
                 return k1_launch_d384_kl16(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
             else
                 return launch_k1<384, 8, 1, KL, MAXONLY, false, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         }
-        case 512: return launch_k1<512, 4, 1, KL, MAXONLY, false, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
+        case 512: return launch_k1<512, 4, 1, KL, MAXONLY, P, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         case 768: return launch_k1<768, 4, 1, KL, MAXONLY, false, COLLECT, false, M>(p, eq, Q, ec, N, part_s, part_i, gthr, st, coll);
         default: return fail(TSIM_EUNSUPPORTED, "cosine_topk: unsupported padded width %d", D);
     }

@@ -110,7 +110,11 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int NST = 2
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
     const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles) {
+    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles, const bf16_t *__restrict__ Wimg) {
+    // Wimg (optional, BN == N): W re-laid at load time as the LDS images of its k-tiles (pack_gemm_w_kernel), so that every
+    // DMA piece of the W operand is 1 KiB of CONTIGUOUS memory.  From row-major W a piece gathers 8 rows x 128 B, and that
+    // shape streams from L2 at half the rate (tools/microbench/dma_stream: 60 vs 115-128 GB/s per CU); W is 3/4 of the bytes
+    // this kernel stages at BM = 128, BN = 384.
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MT = TM / 32, NT = TN / 32;
     constexpr int RB = BK * 2;       // bytes per tile row
@@ -152,14 +156,18 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     }
     const char *xbase = reinterpret_cast<const char *>(X + (int64_t)m0 * K);
     const char *wbase = reinterpret_cast<const char *>(W + (int64_t)n0 * K);
+    const char *wimg = reinterpret_cast<const char *>(Wimg);
+    // source of piece p (this wave's i-th) for k-tile kt
+    auto piece_src = [&](int i, int p, int kt) __attribute__((always_inline)) -> const char * {
+        if (p < XPIECES) return xbase + src_off[i] + kt * (BK * 2);
+        if (wimg) return wimg + (int64_t)kt * W_BYTES + (p - XPIECES) * 1024 + lane * 16;
+        return wbase + src_off[i] + kt * (BK * 2);
+    };
     auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPW_MAX; ++i) {
             const int p = wave + i * NW;
-            if (p < PIECES) {
-                const char *base = p < XPIECES ? xbase : wbase;   // wave-uniform
-                glds16(base + src_off[i] + kt * (BK * 2), smem + stage * STAGE + p * 1024);
-            }
+            if (p < PIECES) glds16(piece_src(i, p, kt), smem + stage * STAGE + p * 1024);
         }
     };
     // fragment address inside a region for tile row `row`, k-step s, lane half h
@@ -177,7 +185,11 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
+#if defined(TSIM_LN_DIAG) && TSIM_LN_DIAG == 3
+    const int nk = 1;   // TIMING-ONLY: prologue + epilogue alone
+#else
     const int nk = K / BK;
+#endif
     if constexpr (NST == 2) {
         issue(0, 0);
     } else {
@@ -203,17 +215,32 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             bf16x8 bx[2][MT], aw[2][NT];
-            load_frags(0, bx[0], aw[0]);
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                if (s + 1 < KSTEPS) load_frags(s + 1, bx[(s + 1) & 1], aw[(s + 1) & 1]);
+#if defined(TSIM_LN_DIAG) && (TSIM_LN_DIAG == 1 || TSIM_LN_DIAG == 4 || TSIM_LN_DIAG == 5)   // TIMING-ONLY: staging alone (no fragment reads, no MFMAs); 4: X pieces only, 5: W pieces only
+            for (int s = 0; s < KSTEPS; ++s)
                 if (kt + 1 < nk) {
 #pragma unroll
                     for (int i = s * PPW_MAX / KSTEPS; i < (s + 1) * PPW_MAX / KSTEPS; ++i) {
                         const int p = wave + i * NW;
-                        if (p < PIECES)
-                            glds16((p < XPIECES ? xbase : wbase) + src_off[i] + (kt + 1) * (BK * 2),
-                                   smem + ((kt + 1) & 1) * STAGE + p * 1024);
+                        if (TSIM_LN_DIAG == 4 && p >= XPIECES) continue;
+                        if (TSIM_LN_DIAG == 5 && p < XPIECES) continue;
+                        if (p < PIECES) glds16(piece_src(i, p, kt + 1), smem + ((kt + 1) & 1) * STAGE + p * 1024);
+                    }
+                }
+            continue;
+#endif
+            load_frags(0, bx[0], aw[0]);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) load_frags(s + 1, bx[(s + 1) & 1], aw[(s + 1) & 1]);
+#if defined(TSIM_LN_DIAG) && TSIM_LN_DIAG == 2   // TIMING-ONLY: no staging inside the loop (stale tiles)
+                if (false) {
+#else
+                if (kt + 1 < nk) {
+#endif
+#pragma unroll
+                    for (int i = s * PPW_MAX / KSTEPS; i < (s + 1) * PPW_MAX / KSTEPS; ++i) {
+                        const int p = wave + i * NW;
+                        if (p < PIECES) glds16(piece_src(i, p, kt + 1), smem + ((kt + 1) & 1) * STAGE + p * 1024);
                     }
                 }
 #pragma unroll
@@ -859,6 +886,18 @@ __device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, 
     (f(std::integral_constant<int, I>{}), ...);
 }
 
+// W [BN rows, K] -> per k-tile of BK the W-region LDS image of gemm_bf16_kernel<.., BN, BK, ..>: 16-byte slot sl of the image
+// (super-row sr = sl >> 4 of 256 B = 256 / (2 BK) tile rows, slot chp = sl & 15) holds chunk ch = chp ^ (sr & 15) of the super-row.
+__global__ __launch_bounds__(256) void pack_gemm_w_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ img, int BN, int BK, int K) {
+    const int slots = BN * BK * 2 / 16;                             // 16-byte slots per k-tile image
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= (int64_t)slots * (K / BK)) return;
+    const int kt = (int)(u / slots), sl = (int)(u % slots);
+    const int cpr = BK * 2 / 16, rps = 256 / (BK * 2);
+    const int sr = sl >> 4, ch = (sl & 15) ^ (sr & 15);
+    const int row = sr * rps + ch / cpr, c = ch % cpr;
+    img[u] = W[((int64_t)row * K + (int64_t)kt * BK) * 2 / 16 + c];
+}
 // W1 [F, 384] -> per 32-row chunk the K1-style LDS image: row rr, 16-byte slot c holds source chunk c ^ (rr & 15) (low 4 bits)
 __global__ __launch_bounds__(256) void pack_ffn_w1_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ img, int F) {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte unit of the image
@@ -1419,6 +1458,7 @@ struct tsim_encoder {
     struct Layer {
         bf16_t *wqkv, *wo, *w1, *w2;
         bf16_t *pqkv = nullptr, *po = nullptr, *p1 = nullptr, *p2 = nullptr;     // tile-major copies for the ping-pong GEMM
+        bf16_t *lo = nullptr, *l2 = nullptr;   // H = 384: O-proj / FFN2 weights as the k-tile LDS images of the LayerNorm GEMM
         uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes (tile-major) ...
         uint8_t *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // ... and E8M0 block scales [out, in/32]
         float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
@@ -1531,7 +1571,8 @@ static int mpnet_bucket(int rel, int num_buckets) {
 
 template <int BM, int BN, int BK, int WM, int WN, int EPI, int NST = 2>
 static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
-                       const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st) {
+                       const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st,
+                       const bf16_t *Wimg = nullptr) {
     constexpr int lds = gemm_lds_bytes<BM, BN, BK, WM, WN, NST>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, BK, WM, WN, EPI, NST>;
@@ -1540,8 +1581,9 @@ static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, cons
     if (N % BN != 0 || K % BK != 0) return fail(TSIM_EUNSUPPORTED, "gemm: N=%d K=%d not tileable by %dx%d", N, K, BN, BK);
     const int mtiles = (M + BM - 1) / BM, ntiles = N / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+    if (Wimg && ntiles != 1) return fail(TSIM_EINVAL, "gemm: a packed W image needs BN == N");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, X, W, bias, res, gamma, beta, eps, out, M, N, K,
-                       mtiles, ntiles);
+                       mtiles, ntiles, Wimg);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -1611,7 +1653,10 @@ static int gemm_plain(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const 
 
 static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, const bf16_t *res,
                        const float *gamma, const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf,
-                       hipStream_t st) {
+                       hipStream_t st, const bf16_t *Wimg = nullptr) {
+    static int use_img = -1;
+    if (use_img < 0) { const char *e = getenv("TSIM_LN_WIMG"); use_img = e ? atoi(e) : 1; }
+    if (!use_img) Wimg = nullptr;
     static int big = -1;
     if (big < 0) { const char *e = getenv("TSIM_GEMM_BIG"); big = e ? atoi(e) : 1; }
     if (big && ybuf && N >= 512 && N % 256 == 0 && gemm_pp_supported(N, K)) {
@@ -1632,7 +1677,7 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
             // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep
             // path issues a k-tile's DMA pieces in one burst ahead of the MFMAs instead of behind each k-step's)
             auto main_launch = [&](int rows) {
-                return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st);
+                return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st, Wimg);
             };
             if (split && full > 0 && rem > 0 && rem <= 96) {
                 const int m_main = full * 128;
@@ -1640,7 +1685,7 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 if (rc) return rc;
                 // (a three-slot ring for the remainder launch measured no different: 2.744-2.751 vs 2.751-2.752 ms per forward)
                 return launch_gemm<32, 384, 64, 1, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
-                                                                  gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st);
+                                                                  gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg);
             }
             return main_launch(M);
         }
@@ -1721,6 +1766,15 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
             if ((rc = repack(d.wo, H, H * 2, (void **)&d.po))) return bail(rc);
             if ((rc = repack(d.w1, F, H * 2, (void **)&d.p1))) return bail(rc);
             if ((rc = repack(d.w2, H, F * 2, (void **)&d.p2))) return bail(rc);
+        }
+        if (!mx && H == 384 && F % 64 == 0) {   // LayerNorm GEMM (BN = 384, BK = 64): W as contiguous k-tile images
+            if ((rc = dev_alloc(e, (size_t)H * H * 2, (void **)&d.lo))) return bail(rc);
+            if ((rc = dev_alloc(e, (size_t)H * F * 2, (void **)&d.l2))) return bail(rc);
+            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * H / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.wo), reinterpret_cast<uint4 *>(d.lo), 384, 64, H);
+            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * F / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l2), 384, 64, F);
+            if (hipGetLastError() != hipSuccess) return bail(fail(TSIM_EHIP, "LayerNorm GEMM weight packing failed"));
         }
         if (!mx && H == 384 && F % 64 == 0 && F <= 4096) {   // fused FFN (ffn_fused_kernel): both matrices as LDS images
             if ((rc = dev_alloc(e, (size_t)F * H * 2, (void **)&d.p1))) return bail(rc);
@@ -1873,7 +1927,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, e->aq, e->as, T, H, st))) return rc;
                 continue;
             }
-            if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st))) return rc;
+            if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st, L.lo))) return rc;
             static int fused = -1;
             // OFF by default: at the bench shape (67 k tokens = 525 blocks of 128 on 256 CUs: three rounds) the fused kernel
             // takes 256 us per layer against 245 us for FFN1 + FFN2 + tail (profiles/README.md, round 2); kept for shapes that
@@ -1884,7 +1938,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 continue;
             }
             if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, nullptr, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st, L.l2))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

@@ -8,14 +8,14 @@
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int NW, int PPW, int NSLOT>
-__global__ __launch_bounds__(NW * 64) void stream(const char *src, size_t span, size_t wg_stride, int tiles, int *sink) {
+__global__ __launch_bounds__(NW * 64) void stream(const char *src, size_t span, size_t wg_stride, int tiles, int *sink, int rot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = NW * PPW * 1024;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char *base = src + (size_t)blockIdx.x * wg_stride;
     auto issue = [&](int t, int slot) __attribute__((always_inline)) {
-        size_t off = ((size_t)t * TILE) % span;
+        size_t off = ((size_t)(t + (int)blockIdx.x * rot) * TILE) % span;   // rot: workgroups start at different tiles of a shared buffer
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off + (wave * PPW + i) * 1024 + lane * 16),
@@ -84,15 +84,15 @@ static void run_rows(const char *name, const char *buf, size_t span, int rs, int
 }
 
 template <int NW, int PPW, int NSLOT>
-static void run(const char *name, const char *buf, size_t span, size_t wg_stride, int grid, int tiles, int *sink) {
+static void run(const char *name, const char *buf, size_t span, size_t wg_stride, int grid, int tiles, int *sink, int rot = 0) {
     constexpr int lds = NSLOT * NW * PPW * 1024;
     auto k = stream<NW, PPW, NSLOT>;
     hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, buf, span, wg_stride, tiles, sink);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, buf, span, wg_stride, tiles, sink, rot);
     hipEventRecord(e0);
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, buf, span, wg_stride, tiles, sink);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, 0, buf, span, wg_stride, tiles, sink, rot);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
@@ -132,6 +132,15 @@ int main() {
     run_rows<8, 3, 3>("W tile 192x64 bf16, K=384", buf, 2 * MB, 768, 256, 4000, sink);
     run_rows<8, 6, 2>("rows 128 B apart (contiguous)", buf, 2 * MB, 128, 256, 2000, sink);
     run_rows<8, 6, 2>("W tile, K=1536, HBM-size span", buf, 1024 * MB, 3072, 256, 2000, sink);
+    // do workgroups that stream the SAME bytes at the SAME time (every GEMM's W operand here) get in each other's way?
+    // rot = 0: lockstep; rot = 5 / 17: workgroup b starts b*rot tiles further into the shared buffer
+    for (int rot : {0, 1, 5, 17}) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "L2 shared 1.2MB rot=%d", rot);
+        run<8, 3, 3>(nm, buf, 50 * 24576, 0, 256, 4000, sink, rot);
+        run<8, 3, 5>(nm, buf, 50 * 24576, 0, 256, 4000, sink, rot);
+        run<8, 6, 3>(nm, buf, 25 * 49152, 0, 256, 2000, sink, rot);
+    }
     hipDeviceSynchronize();
     return 0;
 }

@@ -1673,6 +1673,8 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
             // workgroups), e.g. 525 tiles = 2 rounds + 13 tiles -> 2 rounds + a quarter round.
             static int split = -1;
             if (split < 0) { const char *e = getenv("TSIM_LN_TAIL"); split = e ? atoi(e) : 1; }
+            // (64-token tiles measured slower: 64 x 384 x 32-k with two workgroups per CU 2.96 ms per forward, 64 x 384 x 64-k 3.08,
+            // against 2.74: the W tile is re-staged for half as many tokens)
             const int mt = (M + 127) / 128, full = (mt / 256) * 256, rem = mt - full;
             // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep
             // path issues a k-tile's DMA pieces in one burst ahead of the MFMAs instead of behind each k-step's)

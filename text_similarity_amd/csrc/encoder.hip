@@ -232,6 +232,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 if (s + 1 < KSTEPS) load_frags(s + 1, bx[(s + 1) & 1], aw[(s + 1) & 1]);
+                // (issuing the next k-tile's pieces behind the first one or two k-steps only, instead of all four: measured equal)
 #if defined(TSIM_LN_DIAG) && TSIM_LN_DIAG == 2   // TIMING-ONLY: no staging inside the loop (stale tiles)
                 if (false) {
 #else

@@ -936,7 +936,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
     const uint32_t b1_lds = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + FF_NSLOT * FF_UNIT + FF_XB;
 
     // unit u of phase u/2: even = W1 image of chunk u/2 (producer); odd = W2 image of chunk u/2 - 2 (consumer, two phases behind)
-    auto issue_unit = [&](int u) __attribute__((always_inline)) {
+    // pieces [i0, i1) of this wave's PPU pieces of unit u
+    auto issue_pieces = [&](int u, int i0, int i1) __attribute__((always_inline)) {
         const int uu = u < nunits ? u : nunits - 1;           // past-the-end: re-read the last unit (uniform vmcnt)
         int c = (uu & 1) ? (uu >> 1) - 2 : (uu >> 1);
         c = c < 0 ? 0 : (c >= nchunks ? nchunks - 1 : c);     // units outside the chunk range are never consumed: any valid source
@@ -945,11 +946,19 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
 #ifdef TSIM_FF_DIAG_NODMA   // DIAGNOSTIC (results wrong): the kernel without its W stream
         (void)src; (void)dst;
 #else
-#pragma unroll
-        for (int i = 0; i < PPU; ++i)
+        for (int i = i0; i < i1; ++i)
             glds16(src + (wave * PPU + i) * 1024 + lane * 16, dst + (wave * PPU + i) * 1024);
 #endif
     };
+    auto issue_unit = [&](int u) __attribute__((always_inline)) { issue_pieces(u, 0, PPU); };
+    // Issue schedule inside a phase.  Right behind the barrier every wave of the CU has LDS-DMA to issue, the CU's address path
+    // takes one wave-instruction at a time (~16 cycles per KiB) and a wave whose next instruction is such a load waits for
+    // its turn: with all six pieces up front every wave sat ~500-600 cycles in that queue while the matrix pipe idled (stamps).
+    // So only the unit that is needed NEXT phase goes out at once; the pieces of the unit after it are dropped between the
+    // phase's MFMAs (TSIM_FF_SPREAD=0: the first form).
+#ifndef TSIM_FF_SPREAD
+#define TSIM_FF_SPREAD 1
+#endif
     // b1 -> LDS (read per chunk inside the loop: an ordinary global load there would drain the ring)
     for (int p = wave; p * 256 < F; p += 8)
         if (p * 256 + lane * 4 < F) glds16(b1 + p * 256 + lane * 4, smem + FF_NSLOT * FF_UNIT + FF_XB + p * 1024);
@@ -990,10 +999,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
             __builtin_amdgcn_s_barrier();                      // ... for everyone; everyone is past phase ph-1
             [[maybe_unused]] const unsigned long long t1 = FF_T();
             issue_unit(2 * ph + 3);
-            issue_unit(2 * ph + 4);
+            if constexpr (!MM || !TSIM_FF_SPREAD) issue_unit(2 * ph + 4);
             [[maybe_unused]] const unsigned long long t2 = FF_T();
             f32x16 hacc;
+            [[maybe_unused]] f32x16 hacc1;   // FF_NACC = 2: odd k-steps accumulate here (two independent chains), added at the end
             if constexpr (MM) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) hacc1[q] = 0.f;
                 f32x4 bv[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
@@ -1012,11 +1024,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
             };
             if constexpr (MM) ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
             uint32_t hw[8];   // registers 8s .. 8s+7 of the finished tile, GELU'd and packed: the B fragment of k-step s
-            float gv[16], gxc[16], gu[16], gp[16];   // GELU of chunk ph-1 in 11 stages of 16 independent operations, one
-                                                     // stage behind every second MFMA of the chain (64 issue cycles per stage)
+            // GELU of chunk ph-1 in 11 stages, each cut into two halves of 8 independent operations: ONE half behind EVERY MFMA of
+            // the chain (32 issue cycles: the time the next, dependent MFMA has to wait for its accumulator anyway).  The first
+            // form put a whole 16-operation stage behind every second MFMA: that pair then cost 64 cycles of VALU issue plus the
+            // full dependency stall of the back-to-back MFMA behind it (stamps: 1 989 cycles of work per phase for 768 of MFMA).
+            float gv[2][8], gxc[2][8], gu[2][8], gp[2][8];
             if constexpr (PV) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) gv[q] = hprev[q];
+                for (int q = 0; q < 16; ++q) gv[q >> 3][q & 7] = hprev[q];
             }
             ff_static_for(std::make_integer_sequence<int, KSTEPS>{}, [&](auto sc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc)::value;
@@ -1024,12 +1039,28 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
                     if constexpr (s + PF < KSTEPS) rd(std::integral_constant<int, s + PF>{});
                     constexpr int younger = s + PF < KSTEPS ? PF : KSTEPS - 1 - s;
                     lgkm_wait_counted<younger>(fr[s % (PF + 1)]);
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[s % (PF + 1)]), bx[s], hacc, 0, 0, 0);
+#ifndef TSIM_FF_NACC
+#define TSIM_FF_NACC 2
+#endif
+                    if constexpr (TSIM_FF_NACC == 2 && (s & 1))
+                        hacc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[s % (PF + 1)]), bx[s], hacc1, 0, 0, 0);
+                    else
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[s % (PF + 1)]), bx[s], hacc, 0, 0, 0);
+                    if constexpr (TSIM_FF_SPREAD && (s == 5 || s == 11 || s == 17)) issue_pieces(2 * ph + 4, s / 6, s / 6 + 1);
                 }
-                if constexpr (PV && (s & 1) && s / 2 <= 10) gelu_stage<s / 2, 16>(gv, gxc, gu, gp);
+#ifdef TSIM_FF_GELU_PAIRED   // A/B: the first form
+                if constexpr (PV && (s & 1) && s / 2 <= 10) {
+                    gelu_stage<s / 2, 8>(gv[0], gxc[0], gu[0], gp[0]);
+                    gelu_stage<s / 2, 8>(gv[1], gxc[1], gu[1], gp[1]);
+                }
+#else
+#ifndef TSIM_FF_DIAG_NOGELU   // (defined: TIMING-ONLY, wrong results: the producer without its activation VALU work)
+                if constexpr (PV && s / 2 <= 10) gelu_stage<s / 2, 8>(gv[s & 1], gxc[s & 1], gu[s & 1], gp[s & 1]);
+#endif
+#endif
                 if constexpr (PV && s == 23) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hw[e] = pack_bf16x2(gv[2 * e], gv[2 * e + 1]);
+                    for (int e = 0; e < 8; ++e) hw[e] = pack_bf16x2(gv[(2 * e) >> 3][(2 * e) & 7], gv[(2 * e + 1) >> 3][(2 * e + 1) & 7]);
                 }
             });
             if constexpr (PV) {
@@ -1038,7 +1069,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
                 asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                              ::"v"(slot0 + ((ph - 1) & 1) * 2048), "v"(f0), "v"(f1) : "memory");
             }
-            if constexpr (MM) hprev = hacc;
+            if constexpr (MM) {
+                if constexpr (TSIM_FF_NACC == 2) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) hprev[q] = hacc[q] + hacc1[q];
+                } else {
+                    hprev = hacc;
+                }
+            }
 #ifdef TSIM_PP_STAMPS
             { const unsigned long long t3 = FF_T(); fs_w += t1 - t0; fs_i += t2 - t1; fs_k += t3 - t2; }
 #endif
@@ -1081,7 +1119,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
         __builtin_amdgcn_s_barrier();                          // units landed; the producer's h of chunk ph-2 is written
         [[maybe_unused]] const unsigned long long t1 = FF_T();
         issue_unit(2 * ph + 3);
-        issue_unit(2 * ph + 4);
+        if (ph < 2 || !TSIM_FF_SPREAD) issue_unit(2 * ph + 4);
         [[maybe_unused]] const unsigned long long t2 = FF_T();
         if (ph >= 2) {
             const uint32_t hs = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)(hslot0 + ((ph - 2) & 1) * 2048));
@@ -1107,6 +1145,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
                 lgkm_wait_counted<younger>(fr[n % (PF + 1)]);
                 y[n >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]), (n & 1) ? h1 : h0,
                                                                    y[n >> 1], 0, 0, 0);
+                if constexpr (TSIM_FF_SPREAD && (n == 5 || n == 11 || n == 17)) issue_pieces(2 * ph + 4, n / 6, n / 6 + 1);
             });
         }
 #ifdef TSIM_PP_STAMPS

@@ -720,14 +720,14 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
         const int row = sl >> 4, ch = (sl & 15) ^ (row & 15);
         src_off[i] = row * K * 2 + ch * 16;
     }
-    auto issue = [&](int st, int stage) __attribute__((always_inline)) {
+    auto issue_pieces = [&](int st, int stage, int i0, int i1) __attribute__((always_inline)) {
         const int s2 = st < total ? st : total - 1;           // past-the-end: re-read the last tile (uniform vmcnt)
         const int j = (it0 + s2 / X2_KG) % ntiles, g = s2 % X2_KG;
         const char *base = reinterpret_cast<const char *>(W) + ((int64_t)j * X2_BN * K + g * X2_BK) * 2;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
+        for (int i = i0; i < i1; ++i)
             glds16(base + src_off[i], smem + stage * STAGE + (wave * PPW + i) * 1024);
     };
+    auto issue = [&](int st, int stage) __attribute__((always_inline)) { issue_pieces(st, stage, 0, PPW); };
     // fragment of sub-tile i, k-step ks (of 8 in a tile): row i*32 + r, source chunk 2 ks + h -> slot (2 ks + h) ^ (r & 15)
     int cks[8];
 #pragma unroll
@@ -804,7 +804,14 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 4) wait_vmcnt<PPW + 4>();
             else wait_vmcnt<PPW>();                           // unknown store count: drain (always safe)
             __builtin_amdgcn_s_barrier();
-            issue(st + 2, (stage + 2) % X2_NSTAGE);
+            // Right behind the barrier all eight waves have LDS-DMA to issue and queue at the CU's one address path while the
+            // matrix pipe idles; the tile is not needed for two steps, so its three pieces are dropped between the k-steps'
+            // MFMAs instead (TSIM_X2_SPREAD=0: all three at the head of the step).
+#ifndef TSIM_X2_SPREAD
+#define TSIM_X2_SPREAD 1
+#endif
+            static_assert(PPW == 3, "issue schedule below places three pieces");
+            if constexpr (!TSIM_X2_SPREAD) issue(st + 2, (stage + 2) % X2_NSTAGE);
             const char *ws = smem + stage * STAGE;
             uint32_t pk[8];
 #pragma unroll
@@ -813,6 +820,9 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                 for (int i = 0; i < X2_NSUB; ++i) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8 *>(ws + i * 8192 + cks[ks]);
                     cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bx[g * 8 + ks], cur[i], 0, 0, 0);
+                }
+                if constexpr (TSIM_X2_SPREAD) {
+                    if (ks == 1 || ks == 3 || ks == 5) issue_pieces(st + 2, (stage + 2) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
                 }
                 if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
             }

@@ -243,3 +243,23 @@ def test_results_do_not_depend_on_shard_boundaries():
     ms, mi = ops.topk_merge(ss, ii, 10)
     np.testing.assert_array_equal(mi.cpu().numpy(), full_i)
     np.testing.assert_array_equal(ms.cpu().numpy(), full_s)
+
+
+def test_many_query_blocks_share_corpus_chunks():
+    """Q = 20 000 queries = 79 query blocks against 300 k rows: the main pass aims for 256 workgroups, so the corpus is cut into
+    FEWER chunks than there are XCDs (4) and pairs of XCDs share a chunk and split the query blocks (k1_topk.h block mapping,
+    `nchunks < 8`); the threshold pre-pass and the two-phase pass are on.  Sampled oracle + properties of every list."""
+    N, d, Q, k = 300_000, 128, 20_000, 10
+    g = torch.Generator(device=DEV).manual_seed(2024)
+    cf = torch.randn((N, d), generator=g, device=DEV)
+    qf = torch.randn((Q, d), generator=g, device=DEV)
+    qf[-3:] = cf[[5, N // 2, N - 1]] * 2.0                  # exact neighbours for the very last query block
+    cu, qu = ops.l2norm_rows(cf), ops.l2norm_rows(qf)
+    s, i, st = ops.cosine_topk(qu, cu, d, k, eq_f32=qf, ec_f32=cf, return_status=True)
+    torch.cuda.synchronize()
+    assert i[-3:, 0].tolist() == [5, N // 2, N - 1]
+    assert (s[:, :-1] >= s[:, 1:]).all() and int(i.min()) >= 0 and int(i.max()) < N and int(st.max()) <= 2
+    sel = [0, 255, 256, 9_999, Q - 257, Q - 1]
+    rs, ri = search_ref.cosine_topk_f32(qf[sel].cpu().numpy(), cf.cpu().numpy(), k)
+    np.testing.assert_array_equal(i[sel].cpu().numpy(), ri)
+    np.testing.assert_array_equal(s[sel].cpu().numpy(), rs)

@@ -760,7 +760,7 @@ static inline bool plan_prepass(int64_t Q, int64_t N, const TopkPlan &mainp, Top
 #define TSIM_K1_PREPASS_ROWS 32768
 #endif
     const int64_t S = mainp.nqb >= 4 ? TSIM_K1_PREPASS_ROWS : 65536;
-    int nch = 512 / mainp.nqb;
+    int nch = (512 / mainp.nqb) & ~7;   // a multiple of 8: the same number of chunks on every XCD (block mapping of the kernel)
     if (nch < 16) nch = 16;
     if (nch > S / 64) nch = (int)(S / 64);
     *p = mainp;
@@ -778,23 +778,34 @@ static inline int plan_topk(int64_t Q, int64_t N, int D, int k, TopkPlan *p) {
     p->qpb = D <= 384 ? 256 : 128;
     const int qpb = p->qpb;
     p->nqb = (int)((Q + qpb - 1) / qpb);
-    // enough workgroups to fill 256 CUs a few times over, but chunks as long as possible: the per-lane
-    // selection cost falls with stream length (candidates ~ KL*ln(n/KL))
-    int64_t target = 256;   // one workgroup per CU (LDS allows one resident): 512 measured 3-9 % slower at Q <= 1024, equal at 4096
-    {   // A/B knob (profiles/README.md): workgroups the main pass aims for
+    // One workgroup is resident per CU (128 KiB of LDS) and workgroup b runs on XCD b % 8 (32 CUs), so a pass runs in rounds
+    // of 32 workgroups PER XCD and a nearly empty last round costs a full one.  The block mapping of the kernel gives XCD x the
+    // chunks x, x + 8, ... with all their query blocks (>= 8 chunks), or lets 8 / nchunks XCDs share a chunk and split its
+    // query blocks (< 8 chunks).  Choose the number of chunks that minimises rounds / chunks (time in units of one workgroup's
+    // pass over the whole shard), and among near-equal choices the one with the fewest chunks and rounds: the per-lane selection
+    // cost falls with stream length (candidates ~ KL*ln(n/KL); 512 workgroups measured 3-9 % slower than 256 at Q <= 1 024).
+    // Examples: 16 query blocks -> 16 chunks (2 per XCD x 16 = 32 workgroups per XCD); 5 -> 48 (the old ceil(256 / 5) = 52 put
+    // 7 x 5 = 35 workgroups on XCDs 0-3: two rounds, 1.36 ms instead of 0.85 at Q = 1 280); 9 -> 56 (63 per XCD, two rounds of
+    // 56 chunks instead of two rounds of 29); 157 -> 8 (five rounds for 4.9 of work).
+    int64_t per_xcd = 32;
+    {   // A/B knob: workgroups per round the plan assumes (256 = 32 per XCD)
         static int env_target = -1;
         if (env_target < 0) { const char *e = getenv("TSIM_K1_TARGET_WGS"); env_target = e ? atoi(e) : 0; }
-        if (env_target > 0) target = env_target;
+        if (env_target >= 8) per_xcd = env_target / 8;
     }
-    int64_t nch = (target + p->nqb - 1) / p->nqb;
-    int64_t max_ch = (N + 255) / 256;  // at least 256 rows per chunk
-    if (nch > max_ch) nch = max_ch;
-    if (nch < 1) nch = 1;
-    if (nch < 8) {   // power of two, so that whole XCDs can share a chunk (see the block mapping in the kernel)
-        int p2 = 1;
-        while (p2 < nch) p2 *= 2;
-        nch = p2 <= max_ch ? p2 : (p2 / 2 >= 1 ? p2 / 2 : 1);
-        if (nch > 4 && nch < 8) nch = 4;
+    const int64_t max_ch = (N + 255) / 256;  // at least 256 rows per chunk
+    int64_t nch = 1;
+    double best = 1e30;
+    for (int64_t cand = 1; cand <= 256 && cand <= max_ch; ++cand) {
+        if (cand < 8 && (cand & (cand - 1)) != 0) continue;   // below 8 chunks whole XCDs share a chunk: powers of two only
+        const int64_t wg_xcd = cand >= 8 ? ((cand + 7) / 8) * p->nqb : (p->nqb + (8 / cand) - 1) / (8 / cand);
+        const int64_t rounds = (wg_xcd + per_xcd - 1) / per_xcd;
+        // more rounds of shorter streams must pay for themselves: +6 % per doubling of the round count
+        const double cost = (double)rounds / (double)cand * (1.0 + 0.06 * log2((double)rounds));
+        if (cost < best * 0.985) {
+            best = cost;
+            nch = cand;
+        }
     }
     int64_t rpc = (N + nch - 1) / nch;
     rpc = (rpc + K1_TILE_ROWS - 1) / K1_TILE_ROWS * K1_TILE_ROWS;

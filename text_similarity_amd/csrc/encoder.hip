@@ -680,6 +680,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_xres_kernel(const bf16_t *__rest
     XR_ACC(0, xs_n); XR_ACC(5, xs_x); XR_ACC(1, xs_w); XR_ACC(2, xs_i); XR_ACC(3, xs_c); XR_ACC(4, xs_e); XR_ACC(6, xs_it);
 }
 
+template <int... I, class Fn>
+__device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, Fn &&f) {   // f(integral_constant<I>) for each I
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
 // =====================================================================================================
 // gemm_xres2: the register-resident K = 384 projection with the EPILOGUE OVERLAPPED.
 //
@@ -724,8 +729,12 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
         const int s2 = st < total ? st : total - 1;           // past-the-end: re-read the last tile (uniform vmcnt)
         const int j = (it0 + s2 / X2_KG) % ntiles, g = s2 % X2_KG;
         const char *base = reinterpret_cast<const char *>(W) + ((int64_t)j * X2_BN * K + g * X2_BK) * 2;
+#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 4)   // TIMING-ONLY: no W stream (stale tiles)
+        (void)base;
+#else
         for (int i = i0; i < i1; ++i)
             glds16(base + src_off[i], smem + stage * STAGE + (wave * PPW + i) * 1024);
+#endif
     };
     auto issue = [&](int st, int stage) __attribute__((always_inline)) { issue_pieces(st, stage, 0, PPW); };
     // fragment of sub-tile i, k-step ks (of 8 in a tile): row i*32 + r, source chunk 2 ks + h -> slot (2 ks + h) ^ (r & 15)
@@ -759,13 +768,22 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             bf16_t *dst = out + m * N + ncol + 8 * gq + 8 * h;
+#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)   // TIMING-ONLY: no output stores (one lane keeps the value alive)
+            if (o.x == 0x12345678u && m < 0) *reinterpret_cast<uint4 *>(dst) = o;
+#else
             if (full) *reinterpret_cast<uint4 *>(dst) = o;
             else if (m < M) *reinterpret_cast<uint4 *>(dst) = o;
+#endif
         }
+#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)
+        return 0;
+#endif
         return full ? 2 : -1;
     };
     auto finish2 = [&](float y0, float y1) __attribute__((always_inline)) -> uint32_t {
+#if !(defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 2))   // (bit 2: TIMING-ONLY, no activation function)
         if constexpr (EPI == EPI_GELU) gelu2(y0, y1);
+#endif
         return pack_bf16x2(y0, y1);
     };
 
@@ -814,6 +832,39 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             if constexpr (!TSIM_X2_SPREAD) issue(st + 2, (stage + 2) % X2_NSTAGE);
             const char *ws = smem + stage * STAGE;
             uint32_t pk[8];
+#ifndef TSIM_X2_ASMPIPE
+#define TSIM_X2_ASMPIPE 1
+#endif
+#if TSIM_X2_ASMPIPE
+            // The step's 24 fragment reads (n = 3 ks + i) roll PF reads ahead of their MFMAs with COUNTED lgkmcnt waits, as in the
+            // search kernel's tile loop: hipcc's own schedule of the plain loads below waits lgkmcnt(0) in front of every k-step,
+            // i.e. for the three reads it has just issued (timing-only builds: the bare loop without stores, activation and W
+            // stream ran at 43 % of the MFMA rate).  No other LDS instruction is issued between these reads (LDS-DMA counts in
+            // vmcnt), so the counts are exact.
+            {
+                constexpr int PF = 3, NRD = 8 * X2_NSUB;
+                lds_u32x4 fr[PF + 1];
+                const uint32_t wsl = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem) + stage * STAGE;
+                auto rd = [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int n = decltype(nc)::value;
+                    lds_read_b128_imm<(n % X2_NSUB) * 8192>(fr[n % (PF + 1)], wsl + cks[n / X2_NSUB]);
+                };
+                ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
+                ff_static_for(std::make_integer_sequence<int, NRD>{}, [&](auto nc) __attribute__((always_inline)) {
+                    constexpr int n = decltype(nc)::value;
+                    constexpr int ks = n / X2_NSUB, i = n % X2_NSUB;
+                    if constexpr (n + PF < NRD) rd(std::integral_constant<int, n + PF>{});
+                    constexpr int younger = n + PF < NRD ? PF : NRD - 1 - n;
+                    lgkm_wait_counted<younger>(fr[n % (PF + 1)]);
+                    cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]), bx[g * 8 + ks], cur[i], 0, 0, 0);
+                    if constexpr (i == X2_NSUB - 1) {
+                        if constexpr (TSIM_X2_SPREAD && (ks == 1 || ks == 3 || ks == 5))
+                            issue_pieces(st + 2, (stage + 2) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
+                        if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
+                    }
+                });
+            }
+#else
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -826,6 +877,8 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                 }
                 if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
             }
+#endif
+            (void)ws;
             young2 = young1;
             young1 = 0;
             if constexpr (OLD) young1 = store_sub(pk, old_m0, old_n0 + g * 32);
@@ -892,10 +945,6 @@ __device__ unsigned long long g_ff_stamps[8];
 #else
 #define FF_T() 0ull
 #endif
-template <int... I, class Fn>
-__device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, Fn &&f) {   // f(integral_constant<I>) for each I
-    (f(std::integral_constant<int, I>{}), ...);
-}
 
 // W [BN rows, K] -> per k-tile of BK the W-region LDS image of gemm_bf16_kernel<.., BN, BK, ..>: 16-byte slot sl of the image
 // (super-row sr = sl >> 4 of 256 B = 256 / (2 BK) tile rows, slot chp = sl & 15) holds chunk ch = chp ^ (sr & 15) of the super-row.

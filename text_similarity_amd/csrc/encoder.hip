@@ -294,6 +294,100 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         // tile).  The [BM x N] bf16 tile is contiguous in memory: it comes in by LDS-DMA in whole 1-KiB pieces and
         // goes out as 16-byte row-contiguous stores; the scattered accesses hit LDS instead (16-byte slots XORed with
         // the row so that the 32 rows of a wave spread over the banks).
+#ifndef TSIM_LN_EPI_DIRECT
+#define TSIM_LN_EPI_DIRECT 1
+#endif
+#if TSIM_LN_EPI_DIRECT
+        // DIRECT form (end of round 2): the residual comes in and the result goes out as 16-byte accesses per lane with a
+        // v_permlane32_swap between the half-waves (lane (r, h) touches features 8 (gq + h) .. + 7 of its token's row: 32
+        // contiguous bytes per row and instruction pair), the way gemm_xres2 and the fused FFN kernel store.  No residual tile
+        // DMA, no output tile in LDS, two workgroup barriers less; only the row statistics still cross the four feature waves
+        // through LDS.  (The first form, below, moved both tiles through LDS because 8-byte groups per lane touched 32 cache
+        // lines per instruction; timing-only builds put prologue + epilogue at 43 % of this kernel.)
+        float *red = reinterpret_cast<float *>(smem);            // [2][WAVES_N][BM] partial sums
+        __builtin_amdgcn_s_barrier();                            // every wave is past its last fragment read
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int64_t m = m0 + wm * TM + j * 32 + r;
+            const int64_t mr = m < M ? m : M - 1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq += 2) {
+                    const uint4 o = *reinterpret_cast<const uint4 *>(res + mr * N + n0 + wn * TN + i * 32 + 8 * gq + 8 * h);
+                    auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+                    const uint32_t a0 = s0[0], c0 = s0[1], a1 = s1[0], c1 = s1[1];
+                    acc[i][j][4 * gq + 0] += __uint_as_float(a0 << 16);
+                    acc[i][j][4 * gq + 1] += __uint_as_float(a0 & 0xffff0000u);
+                    acc[i][j][4 * gq + 2] += __uint_as_float(a1 << 16);
+                    acc[i][j][4 * gq + 3] += __uint_as_float(a1 & 0xffff0000u);
+                    acc[i][j][4 * gq + 4] += __uint_as_float(c0 << 16);
+                    acc[i][j][4 * gq + 5] += __uint_as_float(c0 & 0xffff0000u);
+                    acc[i][j][4 * gq + 6] += __uint_as_float(c1 << 16);
+                    acc[i][j][4 * gq + 7] += __uint_as_float(c1 & 0xffff0000u);
+                }
+        }
+        float mean[MT], rstd[MT];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const float v = pass == 0 ? acc[i][j][g] : (acc[i][j][g] - mean[j]) * (acc[i][j][g] - mean[j]);
+                        s += v;
+                    }
+                s += __shfl_xor(s, 32, 64);
+                if (h == 0) red[(pass * WAVES_N + wn) * BM + wm * TM + j * 32 + r] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_N; ++w) s += red[(pass * WAVES_N + w) * BM + wm * TM + j * 32 + r];
+                if (pass == 0)
+                    mean[j] = s / (float)N;
+                else
+                    rstd[j] = 1.0f / sqrtf(s / (float)N + eps);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            float4 gv[4], be[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                gv[gq] = *reinterpret_cast<const float4 *>(gamma + nbase + i * 32 + 8 * gq);
+                be[gq] = *reinterpret_cast<const float4 *>(beta + nbase + i * 32 + 8 * gq);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                uint32_t pk[8];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float y0 = (acc[i][j][4 * gq + 0] - mean[j]) * rstd[j] * gv[gq].x + be[gq].x;
+                    const float y1 = (acc[i][j][4 * gq + 1] - mean[j]) * rstd[j] * gv[gq].y + be[gq].y;
+                    const float y2 = (acc[i][j][4 * gq + 2] - mean[j]) * rstd[j] * gv[gq].z + be[gq].z;
+                    const float y3 = (acc[i][j][4 * gq + 3] - mean[j]) * rstd[j] * gv[gq].w + be[gq].w;
+                    pk[2 * gq] = pack_bf16x2(y0, y1);
+                    pk[2 * gq + 1] = pack_bf16x2(y2, y3);
+                }
+                const int64_t m = m0 + wm * TM + j * 32 + r;
+#pragma unroll
+                for (int gq = 0; gq < 4; gq += 2) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gq], pk[2 * gq + 2], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gq + 1], pk[2 * gq + 3], false, false);
+                    if (m < M)
+                        *reinterpret_cast<uint4 *>(out + m * N + n0 + wn * TN + i * 32 + 8 * gq + 8 * h) =
+                            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+#else
         constexpr int SPR = BN / 8;                       // 16-byte slots per tile row
         constexpr int SWZ = SPR >= 16 ? 15 : SPR - 1;
         constexpr int TILE_B = BM * BN * 2;
@@ -386,6 +480,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                         *reinterpret_cast<const uint4 *>(smem + sl * 16);
             }
         }
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < NT; ++i)

@@ -76,6 +76,10 @@ int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld
  * workspace: tsim_cosine_topk_workspace_bytes(Q, N, k).
  * tsim_cosine_topk(...) == tsim_cosine_topk_ex with NULL float32 matrices and NULL status. */
 size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k);
+/* Introspection (host only, no launch): how the main pass of a search of Q queries against N rows of padded width ld is cut.
+ * plan[0] = query blocks, plan[1] = corpus chunks, plan[2] = rows per chunk, plan[3] = the largest number of workgroups any one
+ * XCD receives (workgroup b runs on XCD b % 8; a round is 32 of them).  Returns TSIM_OK or TSIM_EINVAL. */
+int tsim_cosine_topk_plan(int64_t Q, int64_t N, int ld, int k, int32_t plan[4]);
 int tsim_cosine_topk_ex(const void *eq_unit, const float *eq_f32, int64_t ldq_f32, int64_t Q,
                         const void *ec_unit, const float *ec_f32, int64_t ldc_f32, int64_t N,
                         int d, int ld, int k, float *out_scores, int64_t *out_idx, int32_t *out_status,

@@ -138,3 +138,23 @@ def test_position_table_guard_matches_hf_index_error():
     for cfg, n in ((mp_cfg, 513), (mp_cfg, 514), (bert_cfg, 513)):
         with pytest.raises(ValueError):
             NativeEncoder.check_lengths(cfg, n)
+
+
+def test_main_pass_plan_balances_the_xcds(lib):
+    """plan_topk (csrc/k1_topk.h): workgroup b runs on XCD b % 8 and one workgroup is resident per CU, so a pass runs in rounds
+    of 32 workgroups per XCD.  The chunk count must not leave some XCDs with a nearly empty extra round (round 2 shipped
+    ceil(256 / query blocks) chunks at first: Q = 1 280 -> 52 chunks -> 35 workgroups on four XCDs, 1.36 ms instead of 0.77)."""
+    plan = (ctypes.c_int32 * 4)()
+    for Q in list(range(1, 8193, 97)) + [256, 768, 1280, 2304, 4096, 16384, 40000, 100000]:
+        assert lib.tsim_cosine_topk_plan(Q, 1_000_000, 384, 10, plan) == 0
+        nqb, nch, rpc, per_xcd = plan[0], plan[1], plan[2], plan[3]
+        assert nqb == -(-Q // 256) and nch >= 1 and nch * rpc >= 1_000_000 and rpc % 32 == 0
+        rounds = -(-per_xcd // 32)
+        ideal = nqb * nch / 256.0                       # rounds if the 256 CUs could be filled exactly
+        # time ~ rounds / nch; compare with the best achievable for this many query blocks (all CUs busy, no remainder)
+        assert rounds / nch <= 1.35 * nqb / 256.0 + 1e-9 or rounds == 1, (Q, nqb, nch, per_xcd, rounds, ideal)
+        if rounds == 1 and nqb <= 256:
+            assert per_xcd * 8 >= 0.6 * 256 or nch * rpc < 2 * 256 * 32, (Q, nqb, nch, per_xcd)   # a single round is mostly full
+    # small corpora: at least 256 rows per chunk
+    assert lib.tsim_cosine_topk_plan(64, 1000, 128, 5, plan) == 0 and plan[1] <= 4
+    assert lib.tsim_cosine_topk_plan(0, 1000, 128, 5, plan) == 1

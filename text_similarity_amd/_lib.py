@@ -47,6 +47,7 @@ _SIGS = {
     "tsim_l2norm_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int,
                                    C.c_float, C.c_void_p]),
     "tsim_cosine_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
+    "tsim_cosine_topk_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "tsim_cosine_topk_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),

@@ -885,6 +885,20 @@ static void launch_finalize(const TopkPlan &p, const float *part_s, const int *p
 }
 }  // namespace tsim
 
+extern "C" int tsim_cosine_topk_plan(int64_t Q, int64_t N, int ld, int k, int32_t plan[4]) {
+    if (Q <= 0 || N <= 0 || k <= 0 || k > TOPK_MAX_K || !plan || tsim_pad_dim(ld) != ld)
+        return fail(TSIM_EINVAL, "tsim_cosine_topk_plan: bad arguments (Q=%lld N=%lld ld=%d k=%d)", (long long)Q, (long long)N, ld, k);
+    TopkPlan p;
+    plan_topk(Q, N, ld, k <= TOPK_MAX_LISTS ? k : 10, &p);
+    plan[0] = p.nqb;
+    plan[1] = p.nchunks;
+    plan[2] = p.rows_per_chunk;
+    // block mapping of cos_topk_partial_kernel: >= 8 chunks: XCD x owns chunks x, x+8, ... with all their query blocks;
+    // fewer: 8 / nchunks XCDs share a chunk and split its query blocks
+    plan[3] = p.nchunks >= 8 ? ((p.nchunks + 7) / 8) * p.nqb : (p.nqb + (8 / p.nchunks) - 1) / (8 / p.nchunks);
+    return TSIM_OK;
+}
+
 extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) {
     if (Q <= 0 || N <= 0 || k <= 0 || k > TOPK_MAX_K) return 0;
     SearchWs w;

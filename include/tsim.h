@@ -51,9 +51,12 @@ int tsim_pad_dim(int d);
  * out[r, :d] = half( x[r, :] / max(||x[r, :]||_2, eps) ), out[r, d:ld_out] = 0, evaluated canonically: float64 sum of
  * squares in a fixed order, float64 reciprocal, one rounding float64 -> half (oracle/search_ref.unit_rows is bit-identical).
  * torch divides each operand by max(norm, eps) with eps = 1e-8; a zero row stays zero, so its score
- * against anything is 0.  x_dtype is TSIM_F32 or TSIM_BF16, ld_in its row stride in elements. */
+ * against anything is 0.  x_dtype is TSIM_F32 or TSIM_BF16, ld_in its row stride in elements.
+ * rho_max (device float, may be NULL): atomically raised to the largest rounding residual of the rows written,
+ * rho_r = || out[r] - x[r] / max(||x[r]||, eps) ||_2 (rounded up).  The caller zeroes the word once and may let several calls
+ * accumulate into it (a corpus that grows); tsim_cosine_topk_ex turns it into a PROVEN bound on |MFMA score - exact score|. */
 int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in,
-                     void *out_f16, int ld_out, float eps, void *stream);
+                     void *out_f16, int ld_out, float eps, float *rho_max, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A6/A7/A9  the per-query loop `expand_as -> F.cosine_similarity -> torch.topk`
@@ -66,11 +69,17 @@ int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld
  *     to float32 (oracle/search_ref.exact_cosine) — torch's own float32 evaluation differs from it by rounding only;
  *   - eq_f32 == ec_f32 == NULL: the inner product of the unit rows as stored (oracle/search_ref.canonical_scores).
  * Results are ordered by (score descending, index ascending) — the tie rule torch.topk leaves undefined.
- * Exactness guard: a query whose k-th exact score is not clear of the MFMA scores of the rows that were NOT re-scored
- * (by c1 x the largest |MFMA - exact| difference seen for that query, c1 = 4, env TSIM_GUARD_C1) is searched again: every
- * row above a fixed threshold is collected and re-scored, and if that overflows or still fails the test, the whole shard
- * is scored exactly for that query.  out_status [Q] int32 (may be NULL) reports which pass produced each row:
- * 0 first pass, 1 widened, 2 brute force.
+ * Exactness guard (a proof, not an estimate).  A stored half row is u^ = u + delta with u the exact unit row and
+ * rho = |delta|_2; for any two rows |u^q.u^c - u_q.u_c| <= rho_q + rho_c + rho_q rho_c (Cauchy-Schwarz), u_q.u_c is the
+ * reference's cosine, and the MFMA's float32 accumulation adds at most ld 2^-23 (1+rho_q)(1+rho_c).  eps_q = that bound with
+ * rho_q measured from the query's own two rows and rho_c = *ec_rho_max, the largest residual of the shard's unit rows as
+ * reported by tsim_l2norm_rows / tsim_encoder_forward (NULL: the a-priori bound 2^-11 + sqrt(ld) 2^-25 of a correctly rounded
+ * unit row, about twice as loose).  Every row that was NOT re-scored has an MFMA score <= cut, hence an exact score
+ * <= cut + eps_q: if that is below the k-th exact score the list stands (status 0).  Otherwise EVERY row whose MFMA score
+ * exceeds (k-th exact score - eps_q) is collected and re-scored (status 1); if more than 1 024 rows qualify, or the bound is
+ * seen to fail on a re-scored row (unit rows that are not the images of the float32 rows), the whole shard is scored exactly
+ * for that query (status 2).  With unit rows only (no float32 matrices) the two scores differ by float32 accumulation alone
+ * and eps = max(4 x the largest difference seen, ld 2^-23).  out_status [Q] int32 (may be NULL) reports the pass per query.
  * out_scores [Q, k] float32, out_idx [Q, k] int64 = shard row index + idx_offset (-1 / -inf when the shard has fewer
  * than k rows).  1 <= k <= 64 (k > 28 skips the list kernel: block maxima -> collect -> re-score).
  * workspace: tsim_cosine_topk_workspace_bytes(Q, N, k).
@@ -81,7 +90,7 @@ size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k);
  * XCD receives (workgroup b runs on XCD b % 8; a round is 32 of them).  Returns TSIM_OK or TSIM_EINVAL. */
 int tsim_cosine_topk_plan(int64_t Q, int64_t N, int ld, int k, int32_t plan[4]);
 int tsim_cosine_topk_ex(const void *eq_unit, const float *eq_f32, int64_t ldq_f32, int64_t Q,
-                        const void *ec_unit, const float *ec_f32, int64_t ldc_f32, int64_t N,
+                        const void *ec_unit, const float *ec_f32, int64_t ldc_f32, const float *ec_rho_max, int64_t N,
                         int d, int ld, int k, float *out_scores, int64_t *out_idx, int32_t *out_status,
                         int64_t idx_offset, void *workspace, size_t workspace_bytes, void *stream);
 int tsim_cosine_topk(const void *eq_unit, int64_t Q, const void *ec_unit, int64_t N, int d, int ld,
@@ -172,11 +181,12 @@ void tsim_encoder_destroy(tsim_encoder *enc);
  * max_len = the longest sequence of the batch (sizes the attention grid); max_len (+ pad_id + 1 for MPNet, whose position
  * rows start there) must not exceed max_pos, else TSIM_EINVAL.
  * Outputs (either may be NULL): pooled_f32 [B, hidden] = masked mean-pool (A4), un-normalised like the
- * reference's encode_text; unit_f16 [B, ld_unit] = L2-normalised half rows ready for tsim_cosine_topk;
+ * reference's encode_text; unit_f16 [B, ld_unit] = L2-normalised half rows ready for tsim_cosine_topk, with
+ * unit_rho_max (device float, may be NULL) raised to their largest rounding residual exactly as tsim_l2norm_rows does;
  * last_hidden_bf16 [T, hidden] for tests. */
 int tsim_encoder_forward(tsim_encoder *enc, const int32_t *tok_ids, const int32_t *tok_pos,
                          const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
-                         int32_t max_len, float *pooled_f32, void *unit_f16, int ld_unit,
+                         int32_t max_len, float *pooled_f32, void *unit_f16, int ld_unit, float *unit_rho_max,
                          void *last_hidden_bf16, void *stream);
 
 /* Kernels cannot raise HF's IndexError: a token id outside [0, vocab), a position row outside [0, max_pos) or a token whose

@@ -236,3 +236,68 @@ def mining_search(query_emb: np.ndarray, corpus_emb: np.ndarray, k: int, chunk: 
         vs.append(v)
         ix.append(i)
     return merge_topk(vs, ix, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The exactness guard of the GPU search (text_similarity_amd/csrc/common.h guard_eps, search.hip cos_topk_finalize):
+# restated here so that tests can replay its decisions on the CPU and check the BOUND it rests on.
+#
+# A stored half row is u^ = u + delta, u = x / max(|x|, eps) the exact unit row, rho = |delta|_2.  For two rows
+# |u^q.u^c - u_q.u_c| <= rho_q + rho_c + rho_q rho_c (Cauchy-Schwarz, |u| <= 1), u_q.u_c is the reference's cosine
+# (search_pipeline.py:77), and a float32 accumulation of the ld exact products in any order adds at most
+# ld 2^-23 (1 + rho_q)(1 + rho_c).
+# ---------------------------------------------------------------------------------------------------------------------
+def rho_rows(x: np.ndarray, eps: float = 1e-8) -> np.ndarray:
+    """[rows] float64: || half(u_r) - u_r ||_2, the rounding residual of each row's stored unit image."""
+    u = l2_normalize_f64(x, eps)
+    with np.errstate(over="ignore"):
+        h = u.astype(np.float16).astype(np.float64)
+    return np.sqrt(((h - u) ** 2).sum(-1))
+
+
+def rho_apriori(ld: int) -> float:
+    """Bound on rho for ANY correctly rounded unit row: relative 2^-11 per normal element, 2^-25 per subnormal one."""
+    return float(np.float32(4.8828125e-4) * np.float32(1.000001) + np.sqrt(np.float32(ld)) * np.float32(2.98023224e-8) * np.float32(1.000001))
+
+
+def guard_eps(rho_q, rho_c, ld: int):
+    """The guard's bound on |MFMA score - exact float32 cosine| for a query with residual rho_q against any row with residual
+    <= rho_c (float64 evaluation of common.h guard_eps; the kernel rounds the same expression up to float32)."""
+    rho_q = np.asarray(rho_q, dtype=np.float64)
+    acc = ld * 2.0 ** -23 * (1.0 + rho_q) * (1.0 + rho_c)
+    return (rho_q + rho_c + rho_q * rho_c + acc + 2.0 ** -22) * (1.0 + 1e-6)
+
+
+def mfma_model_scores(q: np.ndarray, c: np.ndarray, order: str = "f64") -> np.ndarray:
+    """[Q,N] float32 model of the selection scores: inner products of the stored half unit rows.
+    order = "f64": exact dot rounded once (the centre of every possible float32 accumulation);
+            "f32seq": float32 accumulation element by element (a worst-ish case for accumulation error)."""
+    uq, uc = unit_rows(q).astype(np.float64), unit_rows(c).astype(np.float64)
+    if order == "f64":
+        return (uq @ uc.T).astype(np.float32)
+    acc = np.zeros((uq.shape[0], uc.shape[0]), dtype=np.float32)
+    for j in range(uq.shape[1]):
+        acc = (acc + (uq[:, j:j + 1] * uc[None, :, j]).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def guard_replay(q: np.ndarray, c: np.ndarray, k: int, KL: int, mode: str = "bound", rho_c=None, c1: float = 4.0):
+    """First pass of tsim_cosine_topk_ex on the CPU for ONE query row q [d]: the KL best rows by model MFMA score are
+    re-scored exactly; returns (first-pass top-k indices, safe?, eps, cut, k-th exact score).
+    mode = "bound": eps = guard_eps(rho_q, rho_c) (the shipped guard);  "sampled": eps = max(c1 x largest |MFMA - exact| seen on
+    the KL candidates, d 2^-24) — the round-2 heuristic, kept to show what the adversarial fixtures defeat."""
+    q = np.asarray(q, dtype=np.float32)[None, :]
+    m = mfma_model_scores(q, c)[0]
+    order = np.lexsort((np.arange(m.size), -m.astype(np.float64)))[:KL]
+    ex = exact_cosine(q, c[order])[0]
+    cut = float(m[order[-1]])
+    rank = np.lexsort((order, -ex.astype(np.float64)))
+    top = order[rank[:k]]
+    sk = float(ex[rank[k - 1]])
+    ld = c.shape[1]
+    if mode == "bound":
+        rc = float(rho_rows(c).max()) if rho_c is None else float(rho_c)
+        eps = float(guard_eps(rho_rows(q)[0], rc, ld))
+    else:
+        eps = max(c1 * float(np.abs(m[order] - ex).max()), ld * 2.0 ** -24)
+    return top, (cut + eps < sk), eps, cut, sk

@@ -48,14 +48,14 @@ def test_argument_validation_returns_error_codes(lib):
     assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 0, p, p, 0, p, 4096, None) == 1
     assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 384, 65, p, p, 0, p, 4096, None) == 1
     # float32 matrices: both or neither; strides at least d
-    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, None, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
-    assert lib.tsim_cosine_topk_ex(p, p, 100, 4, p, p, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
-    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, p, 384, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 3   # workspace
+    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, None, 384, None, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk_ex(p, p, 100, 4, p, p, 384, None, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 1
+    assert lib.tsim_cosine_topk_ex(p, p, 384, 4, p, p, 384, None, 100, 384, 384, 10, p, p, None, 0, p, 4096, None) == 3   # workspace
     assert lib.tsim_cosine_topk(p, 4, p, 0, 384, 384, 10, p, p, 0, p, 4096, None) == 1
     assert lib.tsim_cosine_topk(p, 4, p, 100, 384, 400, 10, p, p, 0, p, 4096, None) == 1
     assert b"tsim_pad_dim" in lib.tsim_last_error()
     assert lib.tsim_cosine_topk(None, 4, p, 100, 384, 384, 10, p, p, 0, p, 4096, None) == 1
-    assert lib.tsim_l2norm_rows(p, 7, 4, 384, 384, p, 384, 1e-8, None) == 1
+    assert lib.tsim_l2norm_rows(p, 7, 4, 384, 384, p, 384, 1e-8, None, None) == 1
     assert lib.tsim_mean_pool(None, 0, p, 1, 1, 1, p, None) == 1
     with pytest.raises(ValueError):
         _lib.check(1, "x")

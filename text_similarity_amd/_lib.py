@@ -45,10 +45,10 @@ _SIGS = {
     "tsim_last_error": (C.c_char_p, []),
     "tsim_pad_dim": (C.c_int, [C.c_int]),
     "tsim_l2norm_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_int,
-                                   C.c_float, C.c_void_p]),
+                                   C.c_float, C.c_void_p, C.c_void_p]),
     "tsim_cosine_topk_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "tsim_cosine_topk_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "tsim_cosine_topk_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+    "tsim_cosine_topk_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
     "tsim_cosine_topk": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
@@ -67,7 +67,7 @@ _SIGS = {
     "tsim_encoder_destroy": (None, [C.c_void_p]),
     "tsim_encoder_error_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "tsim_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
 }
 

@@ -106,6 +106,30 @@ __device__ __forceinline__ unit_t f64_to_f16(double v) {
 }
 __device__ __forceinline__ unit_t canonical_unit_elem(float x, double inv) { return f64_to_f16((double)x * inv); }
 
+// ---- the search's exactness guard (search.hip; restated in oracle/search_ref.guard_eps) ------------------------------------
+// A stored half row is u^ = u + delta, u = x / max(|x|, eps) the exact unit row, rho = |delta|_2 its rounding residual.
+// For two rows, by Cauchy-Schwarz (|u| <= 1):   | u^q . u^c  -  u_q . u_c |  <=  rho_q + rho_c + rho_q rho_c,
+// and u_q . u_c IS the reference's F.cosine_similarity of the float32 rows.  The MFMA score differs from u^q . u^c by the
+// float32 accumulation of ld products that are exact in float32 (11 x 11 significand bits): at most
+// ld * 2^-23 * |u^q| |u^c| for ANY summation order with rounding or truncation to float32 at every step.  One more 2^-22
+// covers the final rounding of the exact score to float32 and a tie on it.  Every constant is rounded UP.
+//   rho_round_up: float upper bound of a float64 residual norm; NaN / oversized values (rows with NaN or inf elements) are
+//                 clamped to 2, which sends every query that meets them to the brute-force pass.
+__device__ __forceinline__ float rho_round_up(double r) {
+    const float f = (float)(r * (1.0 + 1e-6));
+    return f < 2.f ? f : 2.f;
+}
+// a-priori residual bound of a canonical unit row (every element rounded to nearest half): relative 2^-11 per normal element,
+// absolute 2^-25 per subnormal one  ->  rho <= 2^-11 |u| + sqrt(ld) 2^-25.  Used when the caller has no measured rho_max.
+__host__ __device__ __forceinline__ float rho_apriori(int ld) {
+    return 4.8828125e-4f * 1.000001f + sqrtf((float)ld) * 2.98023224e-8f * 1.000001f;
+}
+__device__ __forceinline__ float guard_eps(float rho_q, float rho_c, int ld) {
+    const double acc = (double)ld * 1.1920928955078125e-7 * (1.0 + rho_q) * (1.0 + rho_c);
+    const double e = (double)rho_q + (double)rho_c + (double)rho_q * (double)rho_c + acc + 2.384185791015625e-7;
+    return (float)(e * (1.0 + 1e-6));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // 0.5 x (1 + erf(x / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7, far below bf16 output resolution),
     // raw v_rcp_f32 / v_exp_f32 (1 ulp) with the constants folded: 14 VALU instructions (erff(): ~30; the same formula

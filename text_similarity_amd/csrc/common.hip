@@ -19,5 +19,5 @@ int fail(int code, const char *fmt, ...) {
 }
 }  // namespace tsim
 
-extern "C" int tsim_version(void) { return 101; }
+extern "C" int tsim_version(void) { return 102; }
 extern "C" const char *tsim_last_error(void) { return tsim::g_last_error.c_str(); }

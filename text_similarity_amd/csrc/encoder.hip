@@ -1547,7 +1547,7 @@ template <int NP>   // 16-byte pieces per lane = ceil(H / 512)
 __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restrict__ x,
                                                           const int32_t *__restrict__ cu, int B, int H,
                                                           float *__restrict__ pooled, unit_t *__restrict__ unit,
-                                                          int ld_unit) {
+                                                          int ld_unit, float *__restrict__ rho_max) {
     __shared__ __attribute__((aligned(16))) float rows[4][NP * 512];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
@@ -1607,17 +1607,26 @@ __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restri
             ss = fma((double)v, (double)v, ss);
         }
         const double inv = canonical_inv_norm(ss, 1e-8f);
+        double r2 = 0.0;   // squared rounding residual of the row (the search guard's rho, see tsim_l2norm_rows)
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int f0 = (lane + 64 * p) * 8;
             if (f0 < H) {
                 f16x8 u;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) u[e] = canonical_unit_elem(s[p][e], inv);
+                for (int e = 0; e < 8; ++e) {
+                    u[e] = canonical_unit_elem(s[p][e], inv);
+                    const double de = (double)(float)u[e] - (double)s[p][e] * inv;
+                    r2 = fma(de, de, r2);
+                }
                 *reinterpret_cast<f16x8 *>(unit + (int64_t)b * ld_unit + f0) = u;
             }
         }
         for (int jx = H + lane; jx < ld_unit; jx += 64) unit[(int64_t)b * ld_unit + jx] = 0;
+        if (rho_max) {
+            const float rho = rho_round_up(sqrt(wave_sum_f64(r2)));
+            if (lane == 0) atomicMax(reinterpret_cast<int *>(rho_max), __float_as_int(rho));
+        }
     }
 }
 
@@ -2064,7 +2073,7 @@ extern "C" void tsim_encoder_destroy(tsim_encoder *e) {
 
 extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, const int32_t *tok_pos,
                                     const int32_t *tok_col, const int32_t *cu_seqlens, int32_t T, int32_t B,
-                                    int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit,
+                                    int32_t max_len, float *pooled_f32, void *unit_bf16, int ld_unit, float *unit_rho_max,
                                     void *last_hidden_bf16, void *stream) {
     TSIM_REQUIRE(e && cu_seqlens && (T == 0 || (tok_ids && tok_pos)), "encoder_forward: null pointer");   // T = 0: only empty sequences
     TSIM_REQUIRE(T >= 0 && B >= 0 && T <= e->cfg.max_tokens && B <= e->cfg.max_seqs,
@@ -2141,7 +2150,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     }
     if (pooled_f32 || unit_bf16) {
         const unsigned g = (unsigned)((B + 3) / 4);
-#define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (unit_t *)unit_bf16, ld_unit)
+#define POOL(V) hipLaunchKernelGGL(pool_packed_kernel<V>, dim3(g), dim3(256), 0, st, e->x0, cu_seqlens, B, H, pooled_f32, (unit_t *)unit_bf16, ld_unit, unit_bf16 ? unit_rho_max : nullptr)
         if (H % 8 != 0 || H > 1024 || (unit_bf16 && ld_unit % 8 != 0))
             return fail(TSIM_EUNSUPPORTED, "encoder: pooling needs a hidden size that is a multiple of 8, at most 1024 (got %d)", H);
         if (((uintptr_t)pooled_f32 | (uintptr_t)unit_bf16) & 15)

@@ -26,10 +26,14 @@ __device__ __forceinline__ float load_as_f32<bf16_t>(const bf16_t *p) { return b
 template <>
 __device__ __forceinline__ float load_as_f32<unit_t>(const unit_t *p) { return (float)*p; }
 
+// rho_max (optional): the largest rounding residual rho_r = || half(u_r) - u_r ||_2 of the rows written, u_r = the exact unit
+// row x_r / max(|x_r|, eps) — the quantity the search's exactness guard is built on (guard_eps below).  Accumulated with an
+// atomic max on the float's bit pattern (non-negative floats order like ints), so one word can span many calls (an index
+// that grows): the caller zeroes it once.
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ x, int64_t rows, int d,
                                                           int64_t ld_in, unit_t *__restrict__ out, int ld_out,
-                                                          float eps) {
+                                                          float eps, float *__restrict__ rho_max) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -41,7 +45,21 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T *__restrict__ 
     }
     const double inv = canonical_inv_norm(ss, eps);
     unit_t *o = out + row * (int64_t)ld_out;
-    for (int j = lane; j < ld_out; j += 64) o[j] = j < d ? canonical_unit_elem(load_as_f32<T>(xr + j), inv) : (unit_t)0;
+    double r2 = 0.0;
+    for (int j = lane; j < ld_out; j += 64) {
+        unit_t hv = (unit_t)0;
+        if (j < d) {
+            const double u = (double)load_as_f32<T>(xr + j) * inv;
+            hv = f64_to_f16(u);
+            const double e = (double)(float)hv - u;
+            r2 = fma(e, e, r2);
+        }
+        o[j] = hv;
+    }
+    if (rho_max) {
+        const float rho = rho_round_up(sqrt(wave_sum_f64(r2)));
+        if (lane == 0) atomicMax(reinterpret_cast<int *>(rho_max), __float_as_int(rho));
+    }
 }
 
 // =====================================================================================================
@@ -113,14 +131,47 @@ enum { CTL_NFLAG = 0, CTL_NUNRES = 1, CTL_WORDS = 4 };
 enum { ST_PASS1 = 0, ST_WIDENED = 1, ST_BRUTE = 2 };
 
 struct GuardArgs {
-    float c1;          // eps = max(c1 * largest |MFMA score - exact score| seen for the query, floor)
+    // COS (float32 rows given): eps = guard_eps(rho_q, rho_c, ld) — a BOUND on |MFMA score - exact score| for the query against
+    // every row of the shard (common.h).  rho_q is computed from the query's two rows in the kernel; rho_c = *rho_c_max when
+    // the caller has the measured residual maximum of the shard's unit rows (tsim_l2norm_rows), else the a-priori bound.
+    // Unit rows only: the scores differ by float32 accumulation alone: eps = max(c1 * largest difference seen, floor),
+    // floor = ld * 2^-23 (rigorous for unit rows; c1 covers callers whose rows are not quite unit).
+    float c1;
     float floor;
+    const float *rho_c_max;   // device, or null
+    float rho_c_default;      // rho_apriori(ld)
+    int ld;
     int *ctl;          // CTL_* words
     int *flag_q;       // [Q] flagged queries, compact
     int *flag_thr;     // [Q] per slot: collection threshold as an ordered int (k1_topk.h float_to_ordered)
+    float *flag_eps;   // [Q] per slot: the query's eps (COS)
     int *unres_q;      // [Q] queries left to the brute-force pass, compact
     int *status;       // [Q] or null
 };
+
+// rho of a query row: || stored half row - exact unit row ||_2 from the float32 row already held in `q` (all 64 lanes take part)
+__device__ __forceinline__ float query_rho(const ExactQuery<float> &q, const unit_t *urow, int d, int lane) {
+    double r2 = 0.0;
+    const double inv = 1.0 / q.norm;
+#pragma unroll
+    for (int i = 0; i < XS_MAXI; ++i) {
+        const int j = lane + 64 * i;
+        if (j < d) {
+            const double e = (double)(float)urow[j] - q.v[i] * inv;
+            r2 = fma(e, e, r2);
+        }
+    }
+    return rho_round_up(sqrt(wave_sum_f64(r2)));
+}
+__device__ __forceinline__ float guard_rho_c(const GuardArgs &g) { return g.rho_c_max ? *g.rho_c_max : g.rho_c_default; }
+// collection threshold for "every row whose exact score could reach `target`": MFMA score >= target - eps.  Returned one float
+// below (target - eps) so that the float rounding of the subtraction is on the safe side; eps = inf -> collect everything.
+__device__ __forceinline__ float guard_tau(float target, float eps) {
+    if (!(eps < 3.0e38f) || !(target > -3.0e38f)) return -3.4028234e38f;
+    float tau = float_below((float)((double)target - (double)eps));
+    if ((double)tau + (double)eps >= (double)target) tau = float_below(tau);
+    return tau;
+}
 
 // The KL best entries of a query's partial lists by (MFMA score desc, index asc): lane t < KL returns the t-th
 // (my_i = -1 when there are fewer).  ps / pi: the query's lists, nlists of KL entries each, sorted, padded with (-inf, -1).
@@ -237,6 +288,7 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
                                                                 const int *__restrict__ part_i, int P2,
                                                                 int64_t Q, int64_t N, const T *__restrict__ xq, int64_t ldq,
                                                                 const T *__restrict__ xc, int64_t ldc, int d, int k,
+                                                                const unit_t *__restrict__ uq, const int *__restrict__ gthr,
                                                                 float *__restrict__ out_s,
                                                                 int64_t *__restrict__ out_i,
                                                                 int64_t idx_offset, GuardArgs g) {
@@ -281,24 +333,38 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
         out_s[q * k + lane] = -INFINITY;
         out_i[q * k + lane] = -1;
     }
-    // 4. guard
-    bool safe = N <= KL || nvalid < KL;   // every row of the corpus is a candidate
-    float tau = 0.f;
+    // 4. guard.  Rows that are not among the candidates: either they lost against the KL-th list entry (MFMA score <= it), or
+    // the list kernel dropped them against the query's shared bound, whose final (largest) value is gthr[q] — also when the
+    // bound came from a kernel that accumulates in another order (pre-pass in the 16x16x32 form, lists of 32 in the 32x32x16
+    // form): cut = max of the two bounds whatever their origin.  Fewer than KL entries mean "every row was a candidate" only
+    // if nothing was ever filtered (the bound word still holds its initial value).
+    const int bkey = gthr ? gthr[q] : K1_GTHR_INIT;
+    const bool filtered = bkey > K1_GTHR_INIT;
+    bool safe = N <= KL || (nvalid < KL && !filtered);
+    float tau = 0.f, eps = 0.f;
     if (!safe) {
         const float err = wave_max(lane < nvalid ? fabsf(my_s - cs) : 0.f);
-        const float eps = fmaxf(g.c1 * err, g.floor);
-        const float cut = __shfl(my_s, KL - 1, 64);
-        const unsigned long long kth = __ballot(lane < nvalid && rank == k - 1);   // k <= KL - 4 < nvalid: exactly one lane
-        const float sk = __shfl(cs, __ffsll((long long)kth) - 1, 64);
-        safe = (double)cut + (double)eps < (double)sk;
-        tau = float_below((float)((double)sk - (double)eps));   // rows at or below tau cannot reach sk (strictly)
-        if ((double)tau + (double)eps >= (double)sk) tau = float_below(tau);   // rounding of the float conversion
+        if constexpr (COS) {
+            eps = guard_eps(query_rho(eqr, uq + q * g.ld, d, lane), guard_rho_c(g), g.ld);
+            // the bound must hold on the candidates too; if it does not, the unit rows are not the canonical images of the
+            // float32 rows (or rho_c_max is stale): trust nothing, score the whole shard exactly
+            if (!(err <= eps)) eps = INFINITY;
+        } else {
+            eps = fmaxf(g.c1 * err, g.floor);
+        }
+        float cut = nvalid >= KL ? __shfl(my_s, KL - 1, 64) : -INFINITY;
+        if (filtered) cut = fmaxf(cut, ordered_to_float(bkey));
+        const unsigned long long kth = __ballot(lane < nvalid && rank == k - 1);   // at most one lane
+        const float sk = kth ? __shfl(cs, __ffsll((long long)kth) - 1, 64) : -INFINITY;   // fewer than k candidates: no k-th score
+        safe = kth != 0 && (double)cut + (double)eps < (double)sk;
+        tau = guard_tau(sk, eps);   // rows at or below tau cannot reach sk
     }
     if (lane == 0) {
         if (!safe) {
             const int slot = atomicAdd(g.ctl + CTL_NFLAG, 1);
             g.flag_q[slot] = (int)q;
             g.flag_thr[slot] = float_to_ordered(tau);
+            g.flag_eps[slot] = eps;
         }
         if (g.status) g.status[q] = safe ? ST_PASS1 : ST_WIDENED;
     }
@@ -409,11 +475,18 @@ __global__ __launch_bounds__(256) void widen_finalize_kernel(const unsigned long
                 s_top[t] = s;
             });
             __syncthreads();
-            // guard again, with the threshold the collection used (imported one step lower, k1_topk.h import_threshold)
-            // the sample is larger here (every collected row, not KL candidates), so its largest error is a better estimate
-            // of the bound: half the safety factor of the first pass (not below 1)
+            // guard again with the threshold the collection used: every row that was NOT collected has an MFMA score below
+            // it, hence an exact score below thr + eps.  COS: eps is the query's bound from the first pass (and it must hold on
+            // everything that was re-scored here, else the inputs are inconsistent -> brute force); unit rows only: the largest
+            // difference seen on this larger sample with half the safety factor of the first pass (not below 1).
             const float errmax = fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3]));
-            const float eps = fmaxf(fmaxf(0.5f * g.c1, 1.f) * errmax, g.floor);
+            float eps;
+            if constexpr (COS) {
+                eps = g.flag_eps[slot];
+                if (!(errmax <= eps)) eps = INFINITY;
+            } else {
+                eps = fmaxf(fmaxf(0.5f * g.c1, 1.f) * errmax, g.floor);
+            }
             const float thr = ordered_to_float(g.flag_thr[slot]);
             resolved = n >= k && (double)thr + (double)eps < (double)s_top[k - 1];
         }
@@ -506,18 +579,34 @@ __global__ __launch_bounds__(256) void bf_merge_kernel(int64_t Q, int nch, int k
     }
 }
 
-// every query goes to the widening pass with the threshold found by thr_select minus `margin` (k > 28), or straight to
-// the brute-force pass (all_brute)
-__global__ void flag_all_kernel(int64_t Q, const int *__restrict__ gthr, float margin, bool all_brute, GuardArgs g) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q == 0) g.ctl[all_brute ? CTL_NUNRES : CTL_NFLAG] = (int)Q;
+// k > 28: every query goes to the widening pass (or straight to the brute-force pass: all_brute).  gthr[q] = B, the k-th
+// largest block maximum = a lower bound of the k-th best MFMA score: k rows score >= B on the MFMA, hence >= B - eps exactly,
+// so the k-th best EXACT score is >= B - eps and every row of the exact top-k has an MFMA score >= B - 2 eps: that is the
+// collection threshold.  One wave per query (COS: the query's rho comes from its two rows).
+template <bool COS>
+__global__ __launch_bounds__(256) void flag_all_kernel(int64_t Q, const int *__restrict__ gthr, bool all_brute,
+                                                       const float *__restrict__ xq, int64_t ldq, const unit_t *__restrict__ uq,
+                                                       int d, GuardArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q == 0 && lane == 0) g.ctl[all_brute ? CTL_NUNRES : CTL_NFLAG] = (int)Q;
     if (q >= Q) return;
+    float eps = g.floor;
+    if constexpr (COS) {
+        if (!all_brute) {
+            ExactQuery<float> eqr;
+            exact_load_query<float, true>(eqr, xq + q * ldq, d, lane);
+            eps = guard_eps(query_rho(eqr, uq + q * g.ld, d, lane), guard_rho_c(g), g.ld);
+        }
+    }
+    if (lane != 0) return;
     if (all_brute) {
         g.unres_q[q] = (int)q;
     } else {
         g.flag_q[q] = (int)q;
         const int key = gthr[q];
-        g.flag_thr[q] = key <= K1_GTHR_INIT ? key : float_to_ordered(ordered_to_float(key) - margin);
+        g.flag_thr[q] = key <= K1_GTHR_INIT ? key : float_to_ordered(guard_tau(ordered_to_float(key), 2.f * eps * 1.000001f));
+        g.flag_eps[q] = eps;
     }
     if (g.status) g.status[q] = all_brute ? ST_BRUTE : ST_WIDENED;
 }
@@ -709,7 +798,7 @@ extern "C" int tsim_pad_dim(int d) {
 }
 
 extern "C" int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d, int64_t ld_in, void *out_f16,
-                                int ld_out, float eps, void *stream) {
+                                int ld_out, float eps, float *rho_max, void *stream) {
     TSIM_REQUIRE(x && out_f16, "l2norm_rows: null pointer");
     TSIM_REQUIRE(rows >= 0 && d > 0 && ld_in >= d && ld_out >= d, "l2norm_rows: bad shape rows=%lld d=%d ld_in=%lld ld_out=%d",
                  (long long)rows, d, (long long)ld_in, ld_out);
@@ -717,10 +806,10 @@ extern "C" int tsim_l2norm_rows(const void *x, int x_dtype, int64_t rows, int d,
     const unsigned grid = (unsigned)((rows + 3) / 4);
     if (x_dtype == TSIM_F32)
         hipLaunchKernelGGL(l2norm_rows_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const float *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps);
+                           (const float *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps, rho_max);
     else if (x_dtype == TSIM_BF16)
         hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream),
-                           (const bf16_t *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps);
+                           (const bf16_t *)x, rows, d, ld_in, (unit_t *)out_f16, ld_out, eps, rho_max);
     else
         return fail(TSIM_EINVAL, "l2norm_rows: unknown dtype %d", x_dtype);
     TSIM_HIP_CHECK(hipGetLastError());
@@ -742,7 +831,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // Workspace layout of one search call (byte offsets).
 struct SearchWs {
-    size_t part_s, part_i, gthr, bmax, ctl, flag_q, flag_thr, unres_q, coll_cnt, coll_buf, bf_s, bf_i, total;
+    size_t part_s, part_i, gthr, bmax, ctl, flag_q, flag_thr, flag_eps, unres_q, coll_cnt, coll_buf, bf_s, bf_i, total;
     int bf_nch, bf_rows;
 };
 
@@ -773,6 +862,7 @@ static void plan_workspace(int64_t Q, int64_t N, int k, SearchWs *w) {
     w->ctl = take(CTL_WORDS * 4);
     w->flag_q = take((size_t)Q * 4);
     w->flag_thr = take((size_t)Q * 4);
+    w->flag_eps = take((size_t)Q * 4);
     w->unres_q = take((size_t)Q * 4);
     w->coll_cnt = take((size_t)Q * 4);
     w->coll_buf = take((size_t)Q * COLL_CAP * 8);
@@ -878,10 +968,10 @@ static int search_tail(const SearchWs &w, char *ws, int64_t Q, int64_t N, const 
 
 template <int KL, typename T, bool COS>
 static void launch_finalize(const TopkPlan &p, const float *part_s, const int *part_i, int64_t Q, int64_t N, const T *xq,
-                            int64_t ldq, const T *xc, int64_t ldc, int d, int k, float *out_s, int64_t *out_i,
-                            int64_t idx_offset, const GuardArgs &g, hipStream_t st) {
+                            int64_t ldq, const T *xc, int64_t ldc, int d, int k, const unit_t *uq, const int *gthr, float *out_s,
+                            int64_t *out_i, int64_t idx_offset, const GuardArgs &g, hipStream_t st) {
     hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, part_s, part_i,
-                       p.P2, Q, N, xq, ldq, xc, ldc, d, k, out_s, out_i, idx_offset, g);
+                       p.P2, Q, N, xq, ldq, xc, ldc, d, k, uq, gthr, out_s, out_i, idx_offset, g);
 }
 }  // namespace tsim
 
@@ -907,7 +997,7 @@ extern "C" size_t tsim_cosine_topk_workspace_bytes(int64_t Q, int64_t N, int k) 
 }
 
 extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t ldq_f32, int64_t Q, const void *ec,
-                                   const float *ec_f32, int64_t ldc_f32, int64_t N, int d, int ld, int k,
+                                   const float *ec_f32, int64_t ldc_f32, const float *ec_rho_max, int64_t N, int d, int ld, int k,
                                    float *out_scores, int64_t *out_idx, int32_t *out_status, int64_t idx_offset,
                                    void *workspace, size_t workspace_bytes, void *stream) {
     TSIM_REQUIRE(eq && ec && out_scores && out_idx, "cosine_topk: null pointer");
@@ -935,8 +1025,13 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
 
     GuardArgs g;
     g.c1 = guard_c1();
-    // floor of the error bound: float32 accumulation of d products of unit rows (d * 2^-24, rigorous for unit rows)
-    g.floor = (float)ld * 5.9604645e-8f;
+    // unit rows only: float32 accumulation of ld exact products of unit rows, any order, rounding or truncation per step
+    // (ld * 2^-23 |a||b|, |a|,|b| <= 1 + 2^-10) + the final rounding of the exact score
+    g.floor = (float)ld * 1.1920929e-7f * 1.003f + 2.4e-7f;
+    g.rho_c_max = ec_rho_max;
+    g.rho_c_default = rho_apriori(ld);
+    g.ld = ld;
+    g.flag_eps = reinterpret_cast<float *>(ws + w.flag_eps);
     g.ctl = reinterpret_cast<int *>(ws + w.ctl);
     g.flag_q = reinterpret_cast<int *>(ws + w.flag_q);
     g.flag_thr = reinterpret_cast<int *>(ws + w.flag_thr);
@@ -995,14 +1090,14 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
         if (ev1) TSIM_HIP_CHECK(hipEventRecord(ev1, st));
         if (cosf) {
             if (p.KL == 16) launch_finalize<16, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k,
-                                                             out_scores, out_idx, idx_offset, g, st);
-            else launch_finalize<32, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, out_scores,
-                                                  out_idx, idx_offset, g, st);
+                                                             uq, gthr, out_scores, out_idx, idx_offset, g, st);
+            else launch_finalize<32, float, true>(p, part_s, part_i, Q, N, eq_f32, ldq_f32, ec_f32, ldc_f32, d, k, uq, gthr,
+                                                  out_scores, out_idx, idx_offset, g, st);
         } else {
-            if (p.KL == 16) launch_finalize<16, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores,
-                                                               out_idx, idx_offset, g, st);
-            else launch_finalize<32, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, out_scores, out_idx,
-                                                    idx_offset, g, st);
+            if (p.KL == 16) launch_finalize<16, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, uq, gthr,
+                                                               out_scores, out_idx, idx_offset, g, st);
+            else launch_finalize<32, unit_t, false>(p, part_s, part_i, Q, N, uq, ld, uc, ld, ld, k, uq, gthr, out_scores,
+                                                    out_idx, idx_offset, g, st);
         }
         TSIM_HIP_CHECK(hipGetLastError());
     } else {
@@ -1016,8 +1111,12 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
             hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, fp.P2, Q, k, gthr);
             TSIM_HIP_CHECK(hipGetLastError());
         }
-        const float margin = cosf ? 4e-3f : 2.f * g.floor;   // prior for 2 eps; the guard re-checks with measured errors
-        hipLaunchKernelGGL(flag_all_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, st, Q, gthr, margin, !ok, g);
+        if (cosf)
+            hipLaunchKernelGGL(flag_all_kernel<true>, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, Q, gthr, !ok, eq_f32, ldq_f32,
+                               uq, d, g);
+        else
+            hipLaunchKernelGGL(flag_all_kernel<false>, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, Q, gthr, !ok,
+                               (const float *)nullptr, (int64_t)0, uq, d, g);
         TSIM_HIP_CHECK(hipGetLastError());
         run_collect = ok;
     }
@@ -1031,7 +1130,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
 extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64_t N, int d, int ld, int k,
                                 float *out_scores, int64_t *out_idx, int64_t idx_offset, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    return tsim_cosine_topk_ex(eq, nullptr, 0, Q, ec, nullptr, 0, N, d, ld, k, out_scores, out_idx, nullptr, idx_offset,
+    return tsim_cosine_topk_ex(eq, nullptr, 0, Q, ec, nullptr, 0, nullptr, N, d, ld, k, out_scores, out_idx, nullptr, idx_offset,
                                workspace, workspace_bytes, stream);
 }
 

@@ -26,12 +26,12 @@ import torch
 import torch.distributed as dist
 
 
-def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset):
+def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset, rho_c=None):
     from .. import ops
     if c_f32 is None:                       # unit rows only: q_f32 holds unit float16 rows
         return ops.cosine_topk(q_f32, c_unit, d, k, idx_offset=offset)
     q_unit = ops.l2norm_rows(q_f32)
-    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32)
+    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32, rho_c=rho_c)
 
 
 def _hip_merge(scores: torch.Tensor, idx: torch.Tensor, k: int):
@@ -57,9 +57,12 @@ class ShardedCorpusSearch:
     def __init__(self, corpus_unit_local: torch.Tensor, d: int, row_offset: int,
                  group: Optional[dist.ProcessGroup] = None,
                  local_search: Callable = _hip_local_search, merge: Callable = _hip_merge,
-                 corpus_f32_local: Optional[torch.Tensor] = None):
+                 corpus_f32_local: Optional[torch.Tensor] = None, corpus_rho: Optional[torch.Tensor] = None):
         """``corpus_f32_local`` [n_r, d] float32: the embeddings (scores are then the reference's cosines of float32 rows and
-        queries are passed as float32 embeddings); without it queries are unit float16 rows and scores their inner products."""
+        queries are passed as float32 embeddings); without it queries are unit float16 rows and scores their inner products.
+        ``corpus_rho``: the shard's rounding-residual maximum from ``ops.l2norm_rows(..., return_rho=True)`` (tightens the
+        exactness guard's proven bound; results are exact with or without it)."""
+        self.corpus_rho = corpus_rho
         self.corpus = corpus_unit_local
         self.corpus_f32 = corpus_f32_local
         self.d = int(d)
@@ -118,7 +121,10 @@ class ShardedCorpusSearch:
         if ticket.event is not None:
             torch.cuda.current_stream(q_all.device).wait_event(ticket.event)
             q_all.record_stream(torch.cuda.current_stream(q_all.device))
-        s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset)
+        if self.corpus_rho is not None:
+            s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset, self.corpus_rho)
+        else:
+            s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset)
         if self.world == 1:
             return s, i
         Q = s.shape[0]

@@ -32,6 +32,7 @@ class GpuFlatIndex:
         self._f32: Optional[torch.Tensor] = None       # [capacity, d] float32 rows as given
         self._labels: Optional[torch.Tensor] = None    # [capacity] int64
         self._dead: Optional[torch.Tensor] = None      # [capacity] bool
+        self._rho: Optional[torch.Tensor] = None       # [1] float32: largest rounding residual of any unit row ever stored
         self._n = 0
         self._n_dead = 0
 
@@ -67,7 +68,9 @@ class GpuFlatIndex:
         if lab.numel() != n:
             raise ValueError("ids and data disagree in length")
         xf = x.to(self.device, dtype=torch.float32).contiguous()
-        unit = ops.l2norm_rows(xf)
+        if self._rho is None:
+            self._rho = ops.new_rho(self.device)
+        unit = ops.l2norm_rows(xf, rho=self._rho)       # the word only grows: deleted rows leave the bound conservative
         self._reserve(self._n + n)
         self._rows[self._n:self._n + n] = unit
         self._f32[self._n:self._n + n] = xf
@@ -103,7 +106,7 @@ class GpuFlatIndex:
             Q = q.shape[0]
             return (torch.full((Q, k), -1, dtype=torch.int64, device=self.device),
                     torch.full((Q, k), float("-inf"), device=self.device))
-        s, i = ops.cosine_topk(qn, self._rows[:self._n], self.dim, k, eq_f32=qf, ec_f32=self._f32[:self._n])
+        s, i = ops.cosine_topk(qn, self._rows[:self._n], self.dim, k, eq_f32=qf, ec_f32=self._f32[:self._n], rho_c=self._rho)
         lab = torch.where(i >= 0, self._labels[i.clamp(min=0)], torch.full_like(i, -1))
         return lab, s
 
@@ -124,6 +127,7 @@ class GpuFlatIndex:
         self.dim = int(z["dim"])
         labels = z["labels"]
         self._rows = self._f32 = self._labels = self._dead = None
+        self._rho = ops.new_rho(self.device)
         self._n = self._n_dead = 0
         if "rows_f32" in z.files:
             rows = z["rows_f32"]
@@ -134,7 +138,7 @@ class GpuFlatIndex:
         if n:
             xf = torch.from_numpy(np.ascontiguousarray(rows)).to(self.device)
             self._f32[:n] = xf
-            self._rows[:n] = ops.l2norm_rows(xf)
+            self._rows[:n] = ops.l2norm_rows(xf, rho=self._rho)
         if n:
             self._labels[:n] = torch.from_numpy(labels).to(self.device)
             self._n = n

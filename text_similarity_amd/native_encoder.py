@@ -184,9 +184,10 @@ class NativeEncoder:
 
     def forward_packed(self, flat_ids: torch.Tensor, cu: torch.Tensor, pos: Optional[torch.Tensor] = None,
                        cols: Optional[torch.Tensor] = None, max_len: Optional[int] = None, pooled: bool = True,
-                       unit: bool = False, hidden: bool = False):
+                       unit: bool = False, hidden: bool = False, rho: Optional[torch.Tensor] = None):
         """flat_ids int32 [T], cu int32 [B+1] on the GPU.  Returns dict with 'pooled' f32 [B,H],
-        'unit' float16 [B,pad_dim(H)] (L2-normalised rows for the search kernel), 'hidden' bf16 [T,H] as requested."""
+        'unit' float16 [B,pad_dim(H)] (L2-normalised rows for the search kernel), 'hidden' bf16 [T,H] as requested.
+        ``rho``: a device float32 word raised to the largest rounding residual of the unit rows (ops.l2norm_rows)."""
         ops._need_gpu(flat_ids, cu)
         flat_ids = flat_ids.to(torch.int32).contiguous()
         cu = cu.to(torch.int32).contiguous()
@@ -210,6 +211,7 @@ class NativeEncoder:
                 self._h, flat_ids.data_ptr(), pos.data_ptr(), cols.data_ptr() if cols is not None else None,
                 cu.data_ptr(), T, B, int(max_len), p.data_ptr() if p is not None else None,
                 u.data_ptr() if u is not None else None, u.shape[1] if u is not None else 0,
+                rho.data_ptr() if (rho is not None and u is not None) else None,
                 hd.data_ptr() if hd is not None else None, torch.cuda.current_stream(dev).cuda_stream),
                 "encoder_forward")
         if pooled:

@@ -49,8 +49,18 @@ def pad_dim(d: int) -> int:
     return p
 
 
-def l2norm_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
-    """[rows, d] float32/bf16 -> unit rows in float16 (IEEE half), zero-padded to [rows, pad_dim(d)] (A7 operand prep)."""
+def new_rho(device) -> torch.Tensor:
+    """A zeroed device float for the rounding-residual maximum of a set of unit rows (see :func:`l2norm_rows`)."""
+    return torch.zeros((1,), dtype=torch.float32, device=device)
+
+
+def l2norm_rows(x: torch.Tensor, eps: float = 1e-8, rho: Optional[torch.Tensor] = None, return_rho: bool = False):
+    """[rows, d] float32/bf16 -> unit rows in float16 (IEEE half), zero-padded to [rows, pad_dim(d)] (A7 operand prep).
+
+    ``rho`` (a device float32 tensor of one element, e.g. from :func:`new_rho`) is atomically raised to the largest
+    rounding residual ||half(u_r) - u_r||_2 of the rows written; several calls may accumulate into one word (a corpus built
+    chunk by chunk).  ``return_rho=True`` allocates a fresh word and returns ``(unit_rows, rho)``.  Passing that word to
+    :func:`cosine_topk` as ``rho_c`` gives the search's exactness guard its measured (tightest) error bound."""
     _need_gpu(x)
     if x.dim() != 2:
         raise ValueError("l2norm_rows expects a 2-D tensor")
@@ -61,21 +71,36 @@ def l2norm_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
     ld = pad_dim(d)
     out = torch.empty((rows, ld), dtype=UNIT_DTYPE, device=x.device)
     dt = _lib.TSIM_F32 if x.dtype == torch.float32 else _lib.TSIM_BF16
+    if rho is None and return_rho:
+        rho = new_rho(x.device)
+    if rho is not None:
+        _check_rho(rho, x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.lib().tsim_l2norm_rows(x.data_ptr(), dt, rows, d, x.stride(0), out.data_ptr(), ld, eps,
-                                               _stream(x)), "l2norm_rows")
-    return out
+                                               rho.data_ptr() if rho is not None else 0, _stream(x)), "l2norm_rows")
+    return (out, rho) if return_rho else out
+
+
+def _check_rho(rho, dev):
+    if not isinstance(rho, torch.Tensor) or rho.dtype != torch.float32 or rho.numel() != 1 or rho.device != dev:
+        raise ValueError(f"rho must be a float32 tensor of one element on {dev}")
+
+
+MAX_QUERIES_PER_CALL = 16384    # workspace grows by ~16 KB + 512 k bytes per query: larger query sets are searched in slices
 
 
 def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, idx_offset: int = 0,
                 eq_f32: Optional[torch.Tensor] = None, ec_f32: Optional[torch.Tensor] = None,
-                return_status: bool = False):
+                return_status: bool = False, rho_c: Optional[torch.Tensor] = None):
     """Top-k of every query row against every corpus row: scores [Q,k] f32, idx [Q,k] i64, ordered by (score desc,
     index asc).  ``eq_unit`` / ``ec_unit`` are the unit float16 rows from :func:`l2norm_rows` (what the MFMA kernel streams).
     With ``eq_f32`` / ``ec_f32`` (the float32 embeddings the unit rows were made from) the returned scores are the
     reference's ``F.cosine_similarity`` of the float32 rows (/root/reference/src/pipeline/search_pipeline.py:76-78) and the
-    order is exact for them; without, the inner product of the unit rows as stored.  ``return_status`` adds an int32 [Q]
-    tensor: 0 = first pass, 1 = widened, 2 = brute force (include/tsim.h).  1 <= k <= 64, d <= 768."""
+    order is exact for them; without, the inner product of the unit rows as stored.  ``rho_c``: the residual maximum of
+    ``ec_unit`` from :func:`l2norm_rows` (tightens the guard's proven error bound; without it the a-priori bound of a
+    correctly rounded unit row is used — results are exact either way, more queries take the widening pass).
+    ``return_status`` adds an int32 [Q] tensor: 0 = first pass, 1 = widened, 2 = brute force (include/tsim.h).
+    1 <= k <= 64, d <= 768.  Query sets above MAX_QUERIES_PER_CALL rows are searched in slices (queries are independent)."""
     _need_gpu(eq_unit, ec_unit)
     if eq_unit.dtype != UNIT_DTYPE or ec_unit.dtype != UNIT_DTYPE:
         raise ValueError("cosine_topk expects float16 unit rows from l2norm_rows")
@@ -96,6 +121,8 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
             if t.dtype != torch.float32 or t.dim() != 2 or t.shape != (rows, d) or t.stride(1) != 1 or t.device != dev:
                 raise ValueError(f"cosine_topk: {name} must be float32 [{rows}, {d}] with unit inner stride on {dev}")
         qf, cf, ldq, ldc = eq_f32.data_ptr(), ec_f32.data_ptr(), eq_f32.stride(0), ec_f32.stride(0)
+    if rho_c is not None:
+        _check_rho(rho_c, dev)
     scores = torch.empty((Q, k), dtype=torch.float32, device=dev)
     idx = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.zeros((Q,), dtype=torch.int32, device=dev) if return_status else None
@@ -103,13 +130,18 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
         return (scores, idx, status) if return_status else (scores, idx)
     L = _lib.lib()
     with torch.cuda.device(dev):
-        nbytes = L.tsim_cosine_topk_workspace_bytes(Q, N, k)
+        step = min(Q, MAX_QUERIES_PER_CALL)
+        nbytes = L.tsim_cosine_topk_workspace_bytes(step, N, k)
         if nbytes == 0:
             raise ValueError(f"cosine_topk: unsupported shape Q={Q} N={N} k={k} (1 <= k <= 64)")
         ws = _workspace(dev, nbytes)
-        _lib.check(L.tsim_cosine_topk_ex(eq_unit.data_ptr(), qf, ldq, Q, ec_unit.data_ptr(), cf, ldc, N, d, ld, k,
-                                         scores.data_ptr(), idx.data_ptr(), status.data_ptr() if return_status else 0,
-                                         idx_offset, ws.data_ptr(), ws.numel(), _stream(eq_unit)), "cosine_topk")
+        for q0 in range(0, Q, step):
+            nq = min(step, Q - q0)
+            _lib.check(L.tsim_cosine_topk_ex(eq_unit.data_ptr() + q0 * ld * 2, qf + q0 * ldq * 4 if qf else 0, ldq, nq,
+                                             ec_unit.data_ptr(), cf, ldc, rho_c.data_ptr() if rho_c is not None else 0, N, d, ld, k,
+                                             scores.data_ptr() + q0 * k * 4, idx.data_ptr() + q0 * k * 8,
+                                             status.data_ptr() + q0 * 4 if return_status else 0,
+                                             idx_offset, ws.data_ptr(), ws.numel(), _stream(eq_unit)), "cosine_topk")
     return (scores, idx, status) if return_status else (scores, idx)
 
 

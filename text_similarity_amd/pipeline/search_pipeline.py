@@ -76,8 +76,8 @@ class SentenceMiningPipeline(SearchPipeline):
             if isinstance(chunk, list):
                 chunk = self.model.encode_text(chunk)
             cf = chunk.to(self.params.device, dtype=torch.float32).contiguous()
-            cn = ops.l2norm_rows(cf)
-            s, i = ops.cosine_topk(qn, cn, d, min(k, cn.shape[0]), idx_offset=start, eq_f32=qf, ec_f32=cf)
+            cn, rho = ops.l2norm_rows(cf, return_rho=True)     # rho: the chunk's rounding-residual maximum (guard bound)
+            s, i = ops.cosine_topk(qn, cn, d, min(k, cn.shape[0]), idx_offset=start, eq_f32=qf, ec_f32=cf, rho_c=rho)
             if s.shape[1] < k:   # short last chunk: pad so lists stack
                 pad = k - s.shape[1]
                 s = torch.cat([s, torch.full((s.shape[0], pad), float("-inf"), device=s.device)], 1)

@@ -108,6 +108,11 @@ void tsim_time_next_topk(void *start_event, void *stop_event);
  * entries with idx < 0 are ignored. */
 int tsim_topk_merge(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in,
                     int k_out, float *out_scores, int64_t *out_idx, void *stream);
+/* The same with the lists `list_stride_scores` / `list_stride_idx` ELEMENTS apart (>= Q * k_in): merges the per-rank
+ * [scores | indices] buffers of an all-gather in place, without re-stacking them (distributed/sharded_search.py). */
+int tsim_topk_merge_strided(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in, int k_out,
+                            int64_t list_stride_scores, int64_t list_stride_idx, float *out_scores,
+                            int64_t *out_idx, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A8  cos_sim(a, b)   /root/reference/src/utils/metrics.py:81-101

@@ -40,12 +40,48 @@ def _oracle_merge(scores, idx, k):
     return torch.from_numpy(v), torch.from_numpy(i)
 
 
-def _data(n_total, world):
+def _data(n_total, world, q_total=None):
     corpus = presets.synthetic_embeddings(n_total, 384, "shard/c")
     corpus[n_total - 1] = corpus[3]          # a duplicate living on the LAST shard: tie must resolve to row 3
-    queries = presets.synthetic_embeddings(8 * world, 384, "shard/q")
+    queries = presets.synthetic_embeddings(8 * world if q_total is None else q_total, 384, "shard/q")
     queries[0] = corpus[3]
     return corpus, queries
+
+
+def _uneven_worker(rank, world, port, n_total, q_total, k, out_dir):
+    """world ranks, shards of unequal size (n_total % world != 0) and a query batch that does not split evenly."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = 384
+        corpus, queries = _data(n_total, world, q_total)
+        lo, hi = shard_bounds(n_total, world, rank)
+        counts = [shard_bounds(q_total, world, r)[1] - shard_bounds(q_total, world, r)[0] for r in range(world)]
+        qlo, qhi = shard_bounds(q_total, world, rank)
+        eng = ShardedCorpusSearch(torch.from_numpy(search_ref.unit_rows(corpus[lo:hi])).to(torch.float16), d, lo,
+                                  local_search=_oracle_local, merge=_oracle_merge, corpus_f32_local=torch.from_numpy(corpus[lo:hi]))
+        s, i = eng.search(torch.from_numpy(queries[qlo:qhi]), k, counts=counts)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.numpy(), i=i.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,q_total", [(4, 1003, 35), (4, 1003, 3), (3, 100, 7)])
+def test_uneven_shards_and_query_batches(tmp_path, world, n_total, q_total):
+    """4 ranks, 1 003 rows (shards of 251/251/251/250) and 35 queries (9/9/9/8; 3 queries: one rank has none): the padded
+    exchange and the dropped padding leave exactly the unsharded result, in query order, on every rank."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    k = 10
+    mp.spawn(_uneven_worker, args=(world, port, n_total, q_total, k, str(tmp_path)), nprocs=world, join=True)
+    corpus, queries = _data(n_total, world, q_total)
+    ref_s, ref_i = search_ref.cosine_topk_f32(queries, corpus, k)
+    for r in range(world):
+        got = np.load(tmp_path / f"r{r}.npz")
+        np.testing.assert_array_equal(got["i"], ref_i)
+        np.testing.assert_array_equal(got["s"], ref_s)
+    assert ref_i[0, 0] == 3 and ref_i[0, 1] == n_total - 1
 
 
 def _worker(rank, world, port, n_total, k, mode, out_dir):

@@ -37,7 +37,15 @@ def _rank_main(rank, world, port, n_total, q_total, d, k, mode, out_dir):
         corpus, queries = _data(n_total, q_total, d)
         lo, hi = shard_bounds(n_total, world, rank)
         cf = torch.from_numpy(corpus[lo:hi]).to(dev)
-        eng = ShardedCorpusSearch(ops.l2norm_rows(cf), d, lo, corpus_f32_local=cf)
+        cu, rho = ops.l2norm_rows(cf, return_rho=True)
+        eng = ShardedCorpusSearch(cu, d, lo, corpus_f32_local=cf, corpus_rho=rho)
+        if mode == "uneven":      # 65 queries on 2 ranks: 33 / 32, padded for the exchange and dropped from the result
+            qlo, qhi = shard_bounds(q_total, world, rank)
+            counts = [shard_bounds(q_total, world, r)[1] - shard_bounds(q_total, world, r)[0] for r in range(world)]
+            s, i = eng.search(torch.from_numpy(queries[qlo:qhi]).to(dev), k, counts=counts)
+            torch.cuda.synchronize()
+            np.savez(os.path.join(out_dir, f"r{rank}.npz"), s=s.cpu().numpy(), i=i.cpu().numpy())
+            return
         ql = q_total // world
         q_local = torch.from_numpy(queries[rank * ql:(rank + 1) * ql]).to(dev)
         if mode == "stream":      # pipelined form: second batch = the local slice reversed
@@ -53,11 +61,11 @@ def _rank_main(rank, world, port, n_total, q_total, d, k, mode, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["plain", "stream"])
+@pytest.mark.parametrize("mode", ["plain", "stream", "uneven"])
 def test_two_ranks_with_hip_kernels_equal_one_gpu(tmp_path, mode):
     import torch
     from text_similarity_amd import ops
-    world, n_total, q_total, d, k = 2, 30001, 64, 384, 10
+    world, n_total, q_total, d, k = 2, 30001, (65 if mode == "uneven" else 64), 384, 10
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]

@@ -56,6 +56,8 @@ _SIGS = {
     "tsim_time_next_topk": (None, [C.c_void_p, C.c_void_p]),
     "tsim_topk_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "tsim_topk_merge_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsim_cos_sim": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "tsim_mean_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),

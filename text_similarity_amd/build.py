@@ -28,8 +28,18 @@ def _newer(a, bs):
     return os.path.exists(a) and all(os.path.getmtime(a) >= os.path.getmtime(b) for b in bs)
 
 
+# Timing-only switches that make kernels return WRONG results (they cut work out to see what it costs).  They may only go
+# into a variant build (TSIM_BUILD_TAG set -> libtsim_<tag>.so), never into the product library.
+DIAGNOSTIC_DEFINES = ("TSIM_LN_DIAG", "TSIM_X2_DIAG", "TSIM_FF_DIAG", "TSIM_K1_NOSEL", "TSIM_PP_STAMPS", "TSIM_K1_DIAG",
+                      "TSIM_ATT_DIAG", "TSIM_L_DIAG")
+
+
 def build(force: bool = False, verbose: bool = True, extra_flags=(), only=None) -> str:
     """``only``: compile just these sources (the others must have objects already) — quick iteration on one kernel."""
+    bad = [f for f in extra_flags if f.startswith("-D") and ("DIAG" in f or any(d in f for d in DIAGNOSTIC_DEFINES))]
+    if bad and not TAG:
+        raise RuntimeError(f"{bad}: diagnostic defines produce wrong results; they are refused for the product library — "
+                           "set TSIM_BUILD_TAG=<tag> to build libtsim_<tag>.so beside it")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "tsim.h"))

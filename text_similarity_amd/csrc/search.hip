@@ -657,6 +657,7 @@ __device__ __forceinline__ bool key_before64(float s1, int64_t i1, float s2, int
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ scores,
                                                          const int64_t *__restrict__ idx, int nlists,
                                                          int64_t Q, int k_in, int k_out,
+                                                         int64_t lstride_s, int64_t lstride_i,
                                                          float *__restrict__ out_s,
                                                          int64_t *__restrict__ out_i) {
     const int lane = threadIdx.x & 63;
@@ -670,9 +671,9 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
         int64_t bi = INT64_MAX;
         for (int e = lane; e < E; e += 64) {
             const int l = e / k_in, j = e % k_in;
-            const int64_t off = ((int64_t)l * Q + q) * k_in + j;
-            const float s = scores[off];
-            const int64_t i = idx[off];
+            const int64_t off = q * k_in + j;
+            const float s = scores[(int64_t)l * lstride_s + off];
+            const int64_t i = idx[(int64_t)l * lstride_i + off];
             if (i >= 0 && key_before64(last_s, last_i, s, i) && key_before64(s, i, bs, bi)) {
                 bs = s;
                 bi = i;
@@ -1134,15 +1135,24 @@ extern "C" int tsim_cosine_topk(const void *eq, int64_t Q, const void *ec, int64
                                workspace, workspace_bytes, stream);
 }
 
-extern "C" int tsim_topk_merge(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in, int k_out,
-                               float *out_scores, int64_t *out_idx, void *stream) {
+extern "C" int tsim_topk_merge_strided(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in, int k_out,
+                                       int64_t list_stride_scores, int64_t list_stride_idx, float *out_scores,
+                                       int64_t *out_idx, void *stream) {
     TSIM_REQUIRE(scores && idx && out_scores && out_idx, "topk_merge: null pointer");
     TSIM_REQUIRE(nlists >= 1 && Q >= 0 && k_in >= 1 && k_out >= 1, "topk_merge: bad shape");
+    TSIM_REQUIRE(nlists == 1 || (list_stride_scores >= Q * k_in && list_stride_idx >= Q * k_in),
+                 "topk_merge: list strides %lld / %lld < Q * k_in = %lld", (long long)list_stride_scores,
+                 (long long)list_stride_idx, (long long)(Q * k_in));
     if (Q == 0) return TSIM_OK;
     hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, as_stream(stream), scores,
-                       idx, nlists, Q, k_in, k_out, out_scores, out_idx);
+                       idx, nlists, Q, k_in, k_out, list_stride_scores, list_stride_idx, out_scores, out_idx);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
+}
+
+extern "C" int tsim_topk_merge(const float *scores, const int64_t *idx, int nlists, int64_t Q, int k_in, int k_out,
+                               float *out_scores, int64_t *out_idx, void *stream) {
+    return tsim_topk_merge_strided(scores, idx, nlists, Q, k_in, k_out, Q * k_in, Q * k_in, out_scores, out_idx, stream);
 }
 
 extern "C" int tsim_cos_sim(const float *a, int64_t na, const float *b, int64_t nb, int d, float *out, void *stream) {

@@ -6,8 +6,10 @@ Partitioning: rank r owns corpus rows [offset_r, offset_r + n_r) — the float32
 resident in its HBM; the corpus never moves.  Per query batch there are exactly two exchanges, both tiny and
 latency-bound:
   1. all-gather of the query embeddings   [Q_local, d] float32 per rank  -> [Q, d] everywhere (unit rows are made locally)
-  2. all-gather of per-shard candidates   [Q, k] (score f32, global index i64) per rank, ONE packed buffer
-followed by a k-way merge with the global tie rule (score desc, index asc).  Every shard returns the exact top-k of its
+  2. all-gather of per-shard candidates   [Q, k] (score f32, global index i64) per rank, ONE buffer per rank that the search
+     kernel writes directly ([scores | indices], ops.packed_result_views) and the merge kernel reads in place
+followed by a k-way merge with the global tie rule (score desc, index asc).  On the GPU path ``finish`` issues exactly:
+unit rows of the queries -> search -> all-gather -> merge; no torch arithmetic, no re-packing copies.  Every shard returns the exact top-k of its
 rows with exact scores, so the result is bit-identical to a single-GPU search over the concatenated corpus
 (tests/test_sharded_cpu.py, world_size 2 over gloo; tests/test_sharded_gpu.py with the HIP kernels).
 
@@ -20,18 +22,29 @@ a GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, Iterator, Optional, Tuple
+from typing import Callable, Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset, rho_c=None):
+def _hip_local_search(q_f32, c_unit, c_f32, d, k, offset, rho_c=None, out=None):
     from .. import ops
     if c_f32 is None:                       # unit rows only: q_f32 holds unit float16 rows
-        return ops.cosine_topk(q_f32, c_unit, d, k, idx_offset=offset)
+        return ops.cosine_topk(q_f32, c_unit, d, k, idx_offset=offset, out=out)
     q_unit = ops.l2norm_rows(q_f32)
-    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32, rho_c=rho_c)
+    return ops.cosine_topk(q_unit, c_unit, d, k, idx_offset=offset, eq_f32=q_f32, ec_f32=c_f32, rho_c=rho_c, out=out)
+
+
+def _packed_bytes(Q: int, k: int) -> int:           # == ops.packed_result_bytes (kept here so CPU rehearsals need no GPU ops)
+    return (Q * k * 4 + 7) // 8 * 8 + Q * k * 8
+
+
+def _packed_views(buf: torch.Tensor, Q: int, k: int):
+    so = (Q * k * 4 + 7) // 8 * 8
+    s = buf[..., :Q * k * 4].view(torch.float32)
+    i = buf[..., so:so + Q * k * 8].view(torch.int64)
+    return s.unflatten(-1, (Q, k)), i.unflatten(-1, (Q, k))
 
 
 def _hip_merge(scores: torch.Tensor, idx: torch.Tensor, k: int):
@@ -47,10 +60,10 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class _Ticket:
-    __slots__ = ("q_all", "event")
+    __slots__ = ("q_all", "event", "counts")
 
-    def __init__(self, q_all, event):
-        self.q_all, self.event = q_all, event
+    def __init__(self, q_all, event, counts=None):
+        self.q_all, self.event, self.counts = q_all, event, counts
 
 
 class ShardedCorpusSearch:
@@ -96,11 +109,24 @@ class ShardedCorpusSearch:
         return out.view(q_local.dtype)
 
     # ------------------------------------------------------------------ two-stage API
-    def submit(self, q_local: torch.Tensor) -> _Ticket:
+    def submit(self, q_local: torch.Tensor, counts: Optional[Sequence[int]] = None) -> _Ticket:
         """Start exchange 1 for a batch.  On a GPU it runs on a side stream ordered after the work already queued on the
-        current stream (the encoder that produced ``q_local``), so it overlaps whatever the caller enqueues next."""
+        current stream (the encoder that produced ``q_local``), so it overlaps whatever the caller enqueues next.
+        ``counts``: the number of query rows of EVERY rank when the batch does not split evenly (known without communication,
+        e.g. ``shard_bounds(Q, world, r)``); slices are padded to the longest for the exchange and the padding is dropped
+        from the result."""
+        if counts is not None:
+            counts = [int(c) for c in counts]
+            if len(counts) != self.world or counts[self.rank] != q_local.shape[0]:
+                raise ValueError(f"counts {counts} do not describe {self.world} ranks with {q_local.shape[0]} local rows")
+            qmax = max(counts)
+            if all(c == qmax for c in counts):
+                counts = None
+            elif q_local.shape[0] < qmax:      # pad with zero rows: a zero query scores 0 against everything, then is dropped
+                pad = torch.zeros((qmax - q_local.shape[0], q_local.shape[1]), dtype=q_local.dtype, device=q_local.device)
+                q_local = torch.cat([q_local, pad], 0)
         if self.world == 1 or not q_local.is_cuda:
-            return _Ticket(self.gather_queries(q_local), None)
+            return _Ticket(self.gather_queries(q_local), None, counts)
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=q_local.device)
         main = torch.cuda.current_stream(q_local.device)
@@ -112,7 +138,7 @@ class ShardedCorpusSearch:
             done = torch.cuda.Event()
             done.record(self._comm_stream)
         q_local.record_stream(self._comm_stream)
-        return _Ticket(q_all, done)
+        return _Ticket(q_all, done, counts)
 
     def finish(self, ticket: _Ticket, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """Local search of the gathered batch, exchange 2 (one packed buffer) and the merge: (scores [Q,k], global indices
@@ -121,25 +147,36 @@ class ShardedCorpusSearch:
         if ticket.event is not None:
             torch.cuda.current_stream(q_all.device).wait_event(ticket.event)
             q_all.record_stream(torch.cuda.current_stream(q_all.device))
-        if self.corpus_rho is not None:
-            s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset, self.corpus_rho)
-        else:
-            s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset)
+        Q = q_all.shape[0]
+        hip = self.local_search is _hip_local_search
         if self.world == 1:
+            s, i = (self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset, self.corpus_rho) if hip
+                    else self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset))
             return s, i
-        Q = s.shape[0]
-        # one buffer per rank: [Q, 3k] int32 = score bits | index (lo, hi)
-        packed = torch.cat([s.contiguous().view(torch.int32), i.contiguous().view(torch.int32).view(Q, 2 * k)], dim=1)
-        gathered = torch.empty((self.world * Q, 3 * k), dtype=torch.int32, device=packed.device)
-        self._all_gather(gathered, packed)
-        gathered = gathered.view(self.world, Q, 3 * k)
-        s_all = gathered[:, :, :k].contiguous().view(torch.float32)
-        i_all = gathered[:, :, k:].contiguous().view(torch.int64)
-        return self.merge(s_all, i_all, k)
+        # one buffer per rank, [scores | indices]: the search writes it, the all-gather moves it, the merge reads it in place
+        nb = _packed_bytes(Q, k)
+        mine = torch.empty((nb,), dtype=torch.uint8, device=q_all.device)
+        views = _packed_views(mine, Q, k)
+        if hip:
+            self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset, self.corpus_rho, out=views)
+        else:                                   # injected stand-ins (CPU rehearsals) return fresh tensors
+            s, i = self.local_search(q_all, self.corpus, self.corpus_f32, self.d, k, self.row_offset)
+            views[0].copy_(s)
+            views[1].copy_(i)
+        gathered = torch.empty((self.world, nb), dtype=torch.uint8, device=mine.device)
+        self._all_gather(gathered.view(-1), mine)
+        s_all, i_all = _packed_views(gathered, Q, k)        # [world, Q, k] views, lists nb bytes apart
+        s, i = self.merge(s_all, i_all, k)
+        if ticket.counts is not None:           # uneven batch: drop the padding rows (rank-major order is kept)
+            qmax = Q // self.world
+            keep = [slice(r * qmax, r * qmax + c) for r, c in enumerate(ticket.counts)]
+            s = torch.cat([s[sl] for sl in keep], 0)
+            i = torch.cat([i[sl] for sl in keep], 0)
+        return s, i
 
-    def search(self, q_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, q_local: torch.Tensor, k: int, counts: Optional[Sequence[int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """Every rank passes its slice of the query batch and gets the merged result for ALL queries."""
-        return self.finish(self.submit(q_local), k)
+        return self.finish(self.submit(q_local, counts), k)
 
     def search_stream(self, query_batches: Iterable[torch.Tensor], k: int) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         """Software pipeline over a sequence of batches: the query all-gather of batch i+1 is in flight while batch i is

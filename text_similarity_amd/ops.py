@@ -91,7 +91,8 @@ MAX_QUERIES_PER_CALL = 16384    # workspace grows by ~16 KB + 512 k bytes per qu
 
 def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, idx_offset: int = 0,
                 eq_f32: Optional[torch.Tensor] = None, ec_f32: Optional[torch.Tensor] = None,
-                return_status: bool = False, rho_c: Optional[torch.Tensor] = None):
+                return_status: bool = False, rho_c: Optional[torch.Tensor] = None,
+                out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Top-k of every query row against every corpus row: scores [Q,k] f32, idx [Q,k] i64, ordered by (score desc,
     index asc).  ``eq_unit`` / ``ec_unit`` are the unit float16 rows from :func:`l2norm_rows` (what the MFMA kernel streams).
     With ``eq_f32`` / ``ec_f32`` (the float32 embeddings the unit rows were made from) the returned scores are the
@@ -100,7 +101,9 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
     ``ec_unit`` from :func:`l2norm_rows` (tightens the guard's proven error bound; without it the a-priori bound of a
     correctly rounded unit row is used — results are exact either way, more queries take the widening pass).
     ``return_status`` adds an int32 [Q] tensor: 0 = first pass, 1 = widened, 2 = brute force (include/tsim.h).
-    1 <= k <= 64, d <= 768.  Query sets above MAX_QUERIES_PER_CALL rows are searched in slices (queries are independent)."""
+    1 <= k <= 64, d <= 768.  Query sets above MAX_QUERIES_PER_CALL rows are searched in slices (queries are independent).
+    ``out`` = (scores, idx): preallocated contiguous [Q,k] float32 / int64 tensors to write into (e.g. two views of one
+    exchange buffer, :func:`packed_result_buffer`)."""
     _need_gpu(eq_unit, ec_unit)
     if eq_unit.dtype != UNIT_DTYPE or ec_unit.dtype != UNIT_DTYPE:
         raise ValueError("cosine_topk expects float16 unit rows from l2norm_rows")
@@ -123,8 +126,15 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
         qf, cf, ldq, ldc = eq_f32.data_ptr(), ec_f32.data_ptr(), eq_f32.stride(0), ec_f32.stride(0)
     if rho_c is not None:
         _check_rho(rho_c, dev)
-    scores = torch.empty((Q, k), dtype=torch.float32, device=dev)
-    idx = torch.empty((Q, k), dtype=torch.int64, device=dev)
+    if out is not None:
+        scores, idx = out
+        _need_gpu(scores, idx)
+        if (scores.shape != (Q, k) or idx.shape != (Q, k) or scores.dtype != torch.float32 or idx.dtype != torch.int64
+                or not scores.is_contiguous() or not idx.is_contiguous() or scores.device != dev or idx.device != dev):
+            raise ValueError(f"cosine_topk: out must be contiguous float32 / int64 [{Q}, {k}] tensors on {dev}")
+    else:
+        scores = torch.empty((Q, k), dtype=torch.float32, device=dev)
+        idx = torch.empty((Q, k), dtype=torch.int64, device=dev)
     status = torch.zeros((Q,), dtype=torch.int32, device=dev) if return_status else None
     if Q == 0:
         return (scores, idx, status) if return_status else (scores, idx)
@@ -145,12 +155,35 @@ def cosine_topk(eq_unit: torch.Tensor, ec_unit: torch.Tensor, d: int, k: int, id
     return (scores, idx, status) if return_status else (scores, idx)
 
 
+def packed_result_bytes(Q: int, k: int) -> int:
+    """Bytes of one rank's result buffer: [Q,k] float32 scores, then (8-byte aligned) [Q,k] int64 indices."""
+    return (Q * k * 4 + 7) // 8 * 8 + Q * k * 8
+
+
+def packed_result_views(buf: torch.Tensor, Q: int, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(scores, idx) views of result buffers ``buf`` uint8 [..., packed_result_bytes(Q, k)] (one per leading index): what
+    :func:`cosine_topk` writes through ``out=`` and what :func:`topk_merge` reads in place after an all-gather."""
+    so = (Q * k * 4 + 7) // 8 * 8
+    s = buf[..., :Q * k * 4].view(torch.float32)
+    i = buf[..., so:so + Q * k * 8].view(torch.int64)
+    return s.unflatten(-1, (Q, k)), i.unflatten(-1, (Q, k))
+
+
+def _list_major(t: torch.Tensor) -> bool:
+    """[nlists, Q, k] with each list contiguous (lists may be any distance apart)"""
+    return t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.shape[2] and (t.shape[0] == 1 or t.stride(0) >= t.shape[1] * t.shape[2])
+
+
 def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge per-shard/per-chunk lists (global indices) into [Q,k].  ``scores`` / ``idx`` are either sequences of [Q,k_in]
-    tensors or already stacked [nlists, Q, k_in] tensors (no copy then)."""
+    tensors or [nlists, Q, k_in] tensors; the latter are read in place when every list is contiguous, whatever the distance
+    between lists (e.g. :func:`packed_result_views` of an all-gathered buffer)."""
     s = scores if isinstance(scores, torch.Tensor) else torch.stack([t.contiguous() for t in scores])
     i = idx if isinstance(idx, torch.Tensor) else torch.stack([t.contiguous() for t in idx])
-    s, i = s.contiguous(), i.contiguous()
+    if not _list_major(s):
+        s = s.contiguous()
+    if not _list_major(i):
+        i = i.contiguous()
     _need_gpu(s, i)
     if s.dtype != torch.float32 or i.dtype != torch.int64 or s.shape != i.shape or s.dim() != 3:
         raise ValueError("topk_merge expects float32 scores and int64 indices of one shape [nlists, Q, k_in]")
@@ -158,8 +191,8 @@ def topk_merge(scores, idx, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     out_s = torch.empty((Q, k), dtype=torch.float32, device=s.device)
     out_i = torch.empty((Q, k), dtype=torch.int64, device=s.device)
     with torch.cuda.device(s.device):
-        _lib.check(_lib.lib().tsim_topk_merge(s.data_ptr(), i.data_ptr(), nl, Q, k_in, k, out_s.data_ptr(),
-                                              out_i.data_ptr(), _stream(s)), "topk_merge")
+        _lib.check(_lib.lib().tsim_topk_merge_strided(s.data_ptr(), i.data_ptr(), nl, Q, k_in, k, s.stride(0), i.stride(0),
+                                                      out_s.data_ptr(), out_i.data_ptr(), _stream(s)), "topk_merge")
     return out_s, out_i
 
 

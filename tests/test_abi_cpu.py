@@ -158,3 +158,40 @@ def test_main_pass_plan_balances_the_xcds(lib):
     # small corpora: at least 256 rows per chunk
     assert lib.tsim_cosine_topk_plan(64, 1000, 128, 5, plan) == 0 and plan[1] <= 4
     assert lib.tsim_cosine_topk_plan(0, 1000, 128, 5, plan) == 1
+
+
+def test_backend_tokenizer_path_gives_the_wrapper_ids():
+    """encode_text drives fast tokenizers through their backend encode_batch (one call per chunk, all host cores): the ids
+    must be those of the reference's tokenizer call (/root/reference/src/models/sentence_encoder.py:144-153, padding aside) —
+    truncation to sequence_max_len including [CLS]/[SEP], empty strings, punctuation, accents, long inputs — and the
+    backend's truncation / padding settings must be left as they were."""
+    import numpy as np
+    from transformers import BertTokenizer
+    from text_similarity_amd import presets
+    from text_similarity_amd.models.sentence_encoder import _tokenize_packed
+    tok = BertTokenizer(vocab=presets.synthetic_vocab(30522), do_lower_case=True)
+    sents = presets.synthetic_sentences(300, seed="tokpath", vocab_size=30522)
+    sents[5] = " ".join(["w00017"] * 700)
+    sents[6] = ""
+    sents[7] = "Hello, WORLD! w00001-w00002 héllo 中文 w00003"
+    before = (tok.backend_tokenizer.truncation, tok.backend_tokenizer.padding)
+    for max_len in (256, 16, 3):
+        flat, lens = _tokenize_packed(tok, sents, max_len, 64)
+        ref = tok(text=sents, add_special_tokens=True, padding=False, truncation=True, max_length=max_len,
+                  return_attention_mask=False, return_token_type_ids=False)["input_ids"]
+        assert lens.tolist() == [len(x) for x in ref] and int(lens.max()) <= max_len
+        assert flat.tolist() == [t for x in ref for t in x]
+    tok.backend_tokenizer.no_truncation()
+    flat, lens = _tokenize_packed(tok, sents[:10], 32, 64)
+    assert tok.backend_tokenizer.truncation is None and tok.backend_tokenizer.padding == before[1]
+
+
+def test_build_refuses_diagnostic_defines_for_the_product_library():
+    import pytest
+    from text_similarity_amd import build as b
+    if b.TAG:
+        pytest.skip("a variant build is selected")
+    with pytest.raises(RuntimeError, match="diagnostic"):
+        b.build(extra_flags=["-DTSIM_K1_NOSEL"])
+    with pytest.raises(RuntimeError, match="diagnostic"):
+        b.build(extra_flags=["-DTSIM_LN_DIAG=3"])

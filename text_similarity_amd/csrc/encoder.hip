@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(256) void pool_packed_kernel(const bf16_t *__restri
         for (int jx = H + lane; jx < ld_unit; jx += 64) unit[(int64_t)b * ld_unit + jx] = 0;
         if (rho_max) {
             const float rho = rho_round_up(sqrt(wave_sum_f64(r2)));
-            if (lane == 0) atomicMax(reinterpret_cast<int *>(rho_max), __float_as_int(rho));
+            if (lane == 0) rho_publish(rho_max, rho);
         }
     }
 }

@@ -23,7 +23,34 @@ from .modeling import BaseEncoderModel, _native_from_dir
 def _tokenize_packed(tokenizer, docs: List[str], max_len: int, batch_size: int):
     """Tokenise without padding -> (flat ids int32, lengths).  Same tokenizer kwargs as
     sentence_encoder.py:144-153 except padding: the packed layout has no pad tokens, which is equivalent
-    because padded positions are masked out of attention and pooling."""
+    because padded positions are masked out of attention and pooling.
+
+    Fast (Rust-backed) tokenizers are driven through their backend ``encode_batch`` on the whole chunk: the same code the
+    ``tokenizer(text=...)`` call ends in — identical ids (tests/test_host_cpu.py) — without the per-call Python wrapping
+    (BatchEncoding construction, per-batch option handling), which is single-threaded and was about half of the tokenizer
+    time; the backend itself spreads a batch over the host cores (rayon), so one call per chunk uses all of them."""
+    bt = getattr(tokenizer, "backend_tokenizer", None) if getattr(tokenizer, "is_fast", False) else None
+    if bt is not None and hasattr(bt, "encode_batch"):
+        prev_trunc, prev_pad = bt.truncation, bt.padding
+        try:
+            bt.enable_truncation(max_length=int(max_len), stride=0, strategy="longest_first",
+                                 direction=getattr(tokenizer, "truncation_side", "right"))
+            bt.no_padding()
+            encs = bt.encode_batch(docs, add_special_tokens=True)
+        finally:
+            if prev_trunc is None:
+                bt.no_truncation()
+            else:
+                bt.enable_truncation(**prev_trunc)
+            if prev_pad is not None:
+                bt.enable_padding(**prev_pad)
+        lens = np.fromiter((len(e) for e in encs), dtype=np.int64, count=len(encs))
+        flat = np.empty(int(lens.sum()), dtype=np.int32)
+        o = 0
+        for e, n in zip(encs, lens):
+            flat[o:o + n] = e.ids
+            o += n
+        return flat, lens
     flat, lens = [], []
     for s in range(0, len(docs), batch_size):
         enc = tokenizer(text=docs[s:s + batch_size], add_special_tokens=True, padding=False, truncation=True,

@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t *__restrict
 // HBM/MFMA balance point, so operand reuse through L2 (XCD-aware tile order) matters.
 // =====================================================================================================
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES_LN = 2 };
+#ifndef TSIM_LN_EPI_DIRECT
+#define TSIM_LN_EPI_DIRECT 1   // LayerNorm epilogue: residual / result as 16-byte accesses per lane (0: both tiles through LDS, the first form)
+#endif
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int NST = 2>
 constexpr int gemm_lds_bytes() {
@@ -177,19 +180,33 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         return sr * 256 + ((ch ^ (sr & 15)) << 4);
     };
 
+    // accumulators START from the bias (acc[i][j][g]: feature n0 + wn*TN + i*32 + (g&3) + 8*(g>>2) + 4*h): no bias pass in the
+    // epilogue, and the same arithmetic as ln_rows_gemm_kernel below, whose rows must carry the same bits
     f32x16 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j)
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + n0 + wn * TN + 4 * h + i * 32 + 8 * gq);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-
+            for (int j = 0; j < MT; ++j) {
+                acc[i][j][4 * gq + 0] = bv.x;
+                acc[i][j][4 * gq + 1] = bv.y;
+                acc[i][j][4 * gq + 2] = bv.z;
+                acc[i][j][4 * gq + 3] = bv.w;
+            }
+        }
 #if defined(TSIM_LN_DIAG) && TSIM_LN_DIAG == 3
     const int nk = 1;   // TIMING-ONLY: prologue + epilogue alone
 #else
     const int nk = K / BK;
 #endif
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));   // retire the bias loads before any LDS-DMA is in flight
+    // (Reading the residual tile here, under the first tiles' LDS-DMA latency, instead of in the epilogue measured +0.15 ms per
+    // forward: reverted.)
     if constexpr (NST == 2) {
         issue(0, 0);
     } else {
@@ -272,20 +289,6 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     // ---- epilogue.  acc[i][j][g]: feature n = n0 + wn*TN + i*32 + (g&3) + 8*(g>>2) + 4*h, token m = m0 + wm*TM + j*32 + r
     const int nbase = n0 + wn * TN + 4 * h;
     const int mbase = m0 + wm * TM + r;
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int n = nbase + i * 32 + 8 * gq;
-            const float4 bv = *reinterpret_cast<const float4 *>(bias + n);
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                acc[i][j][4 * gq + 0] += bv.x;
-                acc[i][j][4 * gq + 1] += bv.y;
-                acc[i][j][4 * gq + 2] += bv.z;
-                acc[i][j][4 * gq + 3] += bv.w;
-            }
-        }
 
     if constexpr (EPI == EPI_RES_LN) {
         // Residual add + LayerNorm over the N = BN features of each token (two-pass statistics, fp32), with the
@@ -294,9 +297,6 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         // tile).  The [BM x N] bf16 tile is contiguous in memory: it comes in by LDS-DMA in whole 1-KiB pieces and
         // goes out as 16-byte row-contiguous stores; the scattered accesses hit LDS instead (16-byte slots XORed with
         // the row so that the 32 rows of a wave spread over the banks).
-#ifndef TSIM_LN_EPI_DIRECT
-#define TSIM_LN_EPI_DIRECT 1
-#endif
 #if TSIM_LN_EPI_DIRECT
         // DIRECT form (end of round 2): the residual comes in and the result goes out as 16-byte accesses per lane with a
         // v_permlane32_swap between the half-waves (lane (r, h) touches features 8 (gq + h) .. + 7 of its token's row: 32
@@ -338,8 +338,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
-                        const float v = pass == 0 ? acc[i][j][g] : (acc[i][j][g] - mean[j]) * (acc[i][j][g] - mean[j]);
-                        s += v;
+                        // explicit operations, nothing left to contraction: ln_rows_gemm_kernel repeats them literally
+                        if (pass == 0) {
+                            s += acc[i][j][g];
+                        } else {
+                            const float dlt = acc[i][j][g] - mean[j];
+                            s = fmaf(dlt, dlt, s);
+                        }
                     }
                 s += __shfl_xor(s, 32, 64);
                 if (h == 0) red[(pass * WAVES_N + wn) * BM + wm * TM + j * 32 + r] = s;
@@ -369,10 +374,10 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                 uint32_t pk[8];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const float y0 = (acc[i][j][4 * gq + 0] - mean[j]) * rstd[j] * gv[gq].x + be[gq].x;
-                    const float y1 = (acc[i][j][4 * gq + 1] - mean[j]) * rstd[j] * gv[gq].y + be[gq].y;
-                    const float y2 = (acc[i][j][4 * gq + 2] - mean[j]) * rstd[j] * gv[gq].z + be[gq].z;
-                    const float y3 = (acc[i][j][4 * gq + 3] - mean[j]) * rstd[j] * gv[gq].w + be[gq].w;
+                    const float y0 = fmaf((acc[i][j][4 * gq + 0] - mean[j]) * rstd[j], gv[gq].x, be[gq].x);
+                    const float y1 = fmaf((acc[i][j][4 * gq + 1] - mean[j]) * rstd[j], gv[gq].y, be[gq].y);
+                    const float y2 = fmaf((acc[i][j][4 * gq + 2] - mean[j]) * rstd[j], gv[gq].z, be[gq].z);
+                    const float y3 = fmaf((acc[i][j][4 * gq + 3] - mean[j]) * rstd[j], gv[gq].w, be[gq].w);
                     pk[2 * gq] = pack_bf16x2(y0, y1);
                     pk[2 * gq + 1] = pack_bf16x2(y2, y3);
                 }
@@ -432,8 +437,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                 for (int i = 0; i < NT; ++i)
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
-                        const float v = pass == 0 ? acc[i][j][g] : (acc[i][j][g] - mean[j]) * (acc[i][j][g] - mean[j]);
-                        s += v;
+                        // explicit operations, nothing left to contraction: ln_rows_gemm_kernel repeats them literally
+                        if (pass == 0) {
+                            s += acc[i][j][g];
+                        } else {
+                            const float dlt = acc[i][j][g] - mean[j];
+                            s = fmaf(dlt, dlt, s);
+                        }
                     }
                 s += __shfl_xor(s, 32, 64);
                 if (h == 0) red[(pass * WAVES_N + wn) * BM + wm * TM + j * 32 + r] = s;
@@ -459,10 +469,10 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
                 const float4 be = *reinterpret_cast<const float4 *>(beta + n);
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
-                    const float y0 = (acc[i][j][4 * gq + 0] - mean[j]) * rstd[j] * gv.x + be.x;
-                    const float y1 = (acc[i][j][4 * gq + 1] - mean[j]) * rstd[j] * gv.y + be.y;
-                    const float y2 = (acc[i][j][4 * gq + 2] - mean[j]) * rstd[j] * gv.z + be.z;
-                    const float y3 = (acc[i][j][4 * gq + 3] - mean[j]) * rstd[j] * gv.w + be.w;
+                    const float y0 = fmaf((acc[i][j][4 * gq + 0] - mean[j]) * rstd[j], gv.x, be.x);
+                    const float y1 = fmaf((acc[i][j][4 * gq + 1] - mean[j]) * rstd[j], gv.y, be.y);
+                    const float y2 = fmaf((acc[i][j][4 * gq + 2] - mean[j]) * rstd[j], gv.z, be.z);
+                    const float y3 = fmaf((acc[i][j][4 * gq + 3] - mean[j]) * rstd[j], gv.w, be.w);
                     uint2 o;
                     o.x = pack_bf16x2(y0, y1);
                     o.y = pack_bf16x2(y2, y3);
@@ -1380,6 +1390,200 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
 }
 
 // =====================================================================================================
+// ln_rows_gemm: out = LayerNorm(X W^T + bias + res) for hidden 384 with 256 tokens per workgroup — the O-projection and FFN2 of
+// a MiniLM layer wherever whole rounds of 256-token tiles exist (the rest of the tokens goes through gemm_bf16_kernel<128 / 32,
+// 384, ..>, whose rows carry the same bits: same k order, same MFMA shape, accumulators from the bias, the same statistics).
+//
+// Why (round 3).  LDS is the binding resource of the LayerNorm GEMM: an LDS-DMA write moves 64 B per LDS cycle, a ds_read_b128
+// 256 B, and at BM = 128, BK = 64 a k-tile stages 64 KiB (1 024 LDS cycles) and is read 160 KiB (640) for 1 536 cycles of MFMA
+// per SIMD — measured: staging alone 71 of 80 us (profiles/README.md).  The W tile is 3/4 of the staged bytes and is re-staged for
+// every token tile, so the tile must hold more tokens; gemm_bf16_kernel's 2 x 4 wave grid at BM = 256 needs 192 accumulator
+// registers beside ~110 others and spills (measured 115 us per launch instead of 80).  Here every WAVE owns 32 token rows and ALL
+// 384 features (12 accumulator tiles = 192 VGPRs, the layout of ffn_fused_kernel's consumer): LayerNorm statistics never leave the
+// wave — no barrier, no LDS round trip, no parameter staging in the epilogue — and the k loop is the asm-pipelined form of the
+// other kernels: 32-k tiles (16 KiB of X + 24 KiB of W as packed images) through a three-slot LDS-DMA ring with counted vmcnt (two
+// tiles in flight across the barrier), fragment reads rolling four ahead with counted lgkmcnt, 24 MFMAs per wave and tile.
+// Per k-tile: 40 KiB staged (640 LDS cycles) + 208 KiB read (832) for 1 536 MFMA cycles per SIMD.
+// =====================================================================================================
+constexpr int LR_BK = 32, LR_NST = 3, LR_WBYTES = 384 * LR_BK * 2;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wimg,
+                                                               const float *__restrict__ bias, const bf16_t *__restrict__ res,
+                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                               float eps, bf16_t *__restrict__ out, int M, int K) {
+    constexpr int N = 384, XBYTES = NW * 32 * LR_BK * 2, STAGE = XBYTES + LR_WBYTES;
+    constexpr int XP = XBYTES / 1024, PIECES = STAGE / 1024, PPW = PIECES / NW;   // pieces 0..XP-1: X, the rest: W
+    static_assert(PIECES % NW == 0 && XP == 2 * NW, "every wave issues two X pieces and PPW - 2 W pieces per k-tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * (NW * 32);
+    const int nk = K / LR_BK;
+
+    // accumulators start from the bias: acc[t][q] = output feature 32 t + (q & 3) + 8 (q >> 2) + 4 h of token m0 + 32 wave + r
+    f32x16 acc[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * gq + e] = bv[e];
+        }
+    // LDS image of a region (as gemm_bf16_kernel at BK = 32, so pack_gemm_w_kernel(.., 384, 32, K) images fit): rows of 64 B,
+    // four to a 256-byte super-row; 16-byte slot (sr, chp) holds chunk ch = chp ^ (sr & 15) of the super-row = chunk ch & 3 of
+    // row 4 sr + (ch >> 2).  The permutation goes on the SOURCE address (LDS-DMA writes lane-linearly).
+    const char *xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = (wave + i * NW) * 64 + lane;
+        const int sr = sl >> 4, ch = (sl & 15) ^ (sr & 15);
+        const int row = sr * 4 + (ch >> 2);
+        const int64_t m = m0 + row < M ? m0 + row : M - 1;     // rows past M repeat the last one (never stored)
+        xsrc[i] = reinterpret_cast<const char *>(X) + m * K * 2 + (ch & 3) * 16;
+    }
+    const char *wsrc = reinterpret_cast<const char *>(Wimg) + lane * 16;
+    auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+        const int k2 = kt < nk ? kt : nk - 1;                  // past-the-end: re-read the last tile (uniform vmcnt)
+        char *dst = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + k2 * (LR_BK * 2), dst + (wave + i * NW) * 1024);
+#pragma unroll
+        for (int i = 2; i < PPW; ++i)
+            glds16(wsrc + (int64_t)k2 * LR_WBYTES + (wave + i * NW - XP) * 1024, dst + (wave + i * NW) * 1024);
+    };
+    // fragment read addresses inside a stage: row rho, k-step s, lane half h -> super-row rho >> 2, chunk (rho & 3) * 4 + 2 s + h.
+    // X rows of this wave: rho = 32 wave + r.  W rows of tile t: rho = 32 t + r: the super-row is 8 t + (r >> 2), whose low four
+    // bits depend on the parity of t only -> two address registers per k-step and an immediate of t * 2048.
+    const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+    uint32_t xo[2], wo[2][2];
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+        const int ch = (r & 3) * 4 + 2 * sk + h;
+        xo[sk] = lbase + wave * 2048 + (r >> 2) * 256 + ((ch ^ ((((wave & 1) << 3) + (r >> 2)) & 15)) << 4);
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+            wo[sk][par] = lbase + XBYTES + (r >> 2) * 256 + ((ch ^ (((par << 3) + (r >> 2)) & 15)) << 4);
+    }
+
+    issue(0, 0);
+    issue(1, 1);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(acc[t]));   // retire the bias loads here (and with them tiles 0 and 1)
+    auto do_tile = [&](int kt, auto stc) __attribute__((always_inline)) {
+        constexpr int stage = decltype(stc)::value;
+        wait_vmcnt<PPW>();                 // my pieces of tile kt (those of kt + 1 stay in flight)
+        __builtin_amdgcn_s_barrier();      // everyone's landed; everyone is past tile kt - 1
+        issue(kt + 2, (stage + 2) % LR_NST);
+        constexpr int PF = 4, NRD = 24;
+        lds_u32x4 bfr[2], fr[PF + 1];
+        const uint32_t so = stage * STAGE;
+        lds_read_b128_imm<0>(bfr[0], xo[0] + so);
+        lds_read_b128_imm<0>(bfr[1], xo[1] + so);
+        const uint32_t a00 = wo[0][0] + so, a01 = wo[0][1] + so, a10 = wo[1][0] + so, a11 = wo[1][1] + so;
+        auto rd = [&](auto nc) __attribute__((always_inline)) {            // read n: k-step n / 12, tile n % 12
+            constexpr int n = decltype(nc)::value;
+            constexpr int sk = n / 12, t = n % 12;
+            lds_read_b128_imm<t * 2048>(fr[n % (PF + 1)], sk == 0 ? ((t & 1) ? a01 : a00) : ((t & 1) ? a11 : a10));
+        };
+        ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
+        ff_static_for(std::make_integer_sequence<int, NRD>{}, [&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n + PF < NRD) rd(std::integral_constant<int, n + PF>{});
+            constexpr int younger = n + PF < NRD ? PF : NRD - 1 - n;
+            lgkm_wait_counted<younger>(fr[n % (PF + 1)]);                  // ... and everything older: both X fragments
+            if constexpr (n == 0) { asm volatile("" : "+v"(bfr[0])); asm volatile("" : "+v"(bfr[1])); }
+            acc[n % 12] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]),
+                                                                   __builtin_bit_cast(bf16x8, bfr[n / 12]), acc[n % 12], 0, 0, 0);
+        });
+    };
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        do_tile(kt, std::integral_constant<int, 0>{});
+        do_tile(kt + 1, std::integral_constant<int, 1>{});
+        do_tile(kt + 2, std::integral_constant<int, 2>{});
+    }
+    if (kt < nk) do_tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < nk) do_tile(kt + 1, std::integral_constant<int, 1>{});
+    wait_vmcnt<0>();   // past-the-end tiles must not outlive the workgroup
+
+    // ---------------------------------------------------------------- epilogue: + residual, LayerNorm, store (wave-local)
+    // + residual: the lane's 16 bytes are the 8 features of group gq + h; the swap turns them into the accumulator layout
+    const int64_t m = m0 + wave * 32 + r;
+    const bool live = m < M;
+    const int64_t mr = live ? m : M - 1;
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            const uint4 o = *reinterpret_cast<const uint4 *>(res + mr * N + 32 * t + 8 * gq + 8 * h);
+            auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+            const uint32_t a0 = s0[0], c0 = s0[1], a1 = s1[0], c1 = s1[1];
+            acc[t][4 * gq + 0] += __uint_as_float(a0 << 16);
+            acc[t][4 * gq + 1] += __uint_as_float(a0 & 0xffff0000u);
+            acc[t][4 * gq + 2] += __uint_as_float(a1 << 16);
+            acc[t][4 * gq + 3] += __uint_as_float(a1 & 0xffff0000u);
+            acc[t][4 * gq + 4] += __uint_as_float(c0 << 16);
+            acc[t][4 * gq + 5] += __uint_as_float(c0 & 0xffff0000u);
+            acc[t][4 * gq + 6] += __uint_as_float(c1 << 16);
+            acc[t][4 * gq + 7] += __uint_as_float(c1 & 0xffff0000u);
+        }
+    // two-pass statistics in the association order of gemm_bf16_kernel<.., 384, .., WAVES_N = 4, ..>: four groups of three
+    // sub-tiles (there: one wave each), each summed tile by tile, register by register, then across the half-waves, then
+    // ((0 + g0) + g1) + g2) + g3
+    float mean, rstd;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            float sg = 0.f;
+#pragma unroll
+            for (int t = 3 * w; t < 3 * w + 3; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (pass == 0) {
+                        sg += acc[t][q];
+                    } else {
+                        const float dlt = acc[t][q] - mean;
+                        sg = fmaf(dlt, dlt, sg);
+                    }
+                }
+            sg += __shfl_xor(sg, 32, 64);
+            tot += sg;
+        }
+        if (pass == 0)
+            mean = tot / (float)N;
+        else
+            rstd = 1.0f / sqrtf(tot / (float)N + eps);
+    }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int n = 32 * t + 8 * gq + 4 * h;
+            const f32x4 gv = *reinterpret_cast<const f32x4 *>(gamma + n), bv = *reinterpret_cast<const f32x4 *>(beta + n);
+            const float o0 = fmaf((acc[t][4 * gq + 0] - mean) * rstd, gv[0], bv[0]);
+            const float o1 = fmaf((acc[t][4 * gq + 1] - mean) * rstd, gv[1], bv[1]);
+            const float o2 = fmaf((acc[t][4 * gq + 2] - mean) * rstd, gv[2], bv[2]);
+            const float o3 = fmaf((acc[t][4 * gq + 3] - mean) * rstd, gv[3], bv[3]);
+            pk[2 * gq] = pack_bf16x2(o0, o1);
+            pk[2 * gq + 1] = pack_bf16x2(o2, o3);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gq], pk[2 * gq + 2], false, false);
+            auto s1w = __builtin_amdgcn_permlane32_swap(pk[2 * gq + 1], pk[2 * gq + 3], false, false);
+            if (live) *reinterpret_cast<uint4 *>(out + m * N + 32 * t + 8 * gq + 8 * h) = make_uint4(s0[0], s1w[0], s0[1], s1w[1]);
+        }
+    }
+}
+
+// =====================================================================================================
 // attention on packed tokens (MFMA).  One wave per (sequence, head, block of 32 queries); a workgroup = 4 heads.
 //   S^T = K Q^T   v_mfma_f32_32x32x16_bf16 with A = K rows, B = Q rows: the QUERY lands on the lane (column), 16 keys
 //                 in the accumulator registers -> softmax statistics are lane-local plus one cross-half shuffle;
@@ -1662,6 +1866,7 @@ struct tsim_encoder {
         bf16_t *wqkv, *wo, *w1, *w2;
         bf16_t *pqkv = nullptr, *po = nullptr, *p1 = nullptr, *p2 = nullptr;     // tile-major copies for the ping-pong GEMM
         bf16_t *lo = nullptr, *l2 = nullptr;   // H = 384: O-proj / FFN2 weights as the k-tile LDS images of the LayerNorm GEMM
+        bf16_t *lo32 = nullptr, *l232 = nullptr;   // ... and as 32-k images for ln_rows_gemm_kernel
         uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes (tile-major) ...
         uint8_t *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // ... and E8M0 block scales [out, in/32]
         float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
@@ -1840,6 +2045,19 @@ static int ffn_fused(const bf16_t *X, const bf16_t *W1img, const bf16_t *W2img, 
     return TSIM_OK;
 }
 
+// whole 256-token tiles of a LayerNorm GEMM of width 384 (tiles * 256 <= M rows)
+static int ln_rows_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias, const bf16_t *res, const float *gamma,
+                        const float *beta, float eps, bf16_t *out, int tiles, int M, int K, hipStream_t st) {
+    constexpr int lds = LR_NST * (8 * 32 * LR_BK * 2 + LR_WBYTES);   // 120 KiB
+    auto kern = ln_rows_gemm_kernel<8>;
+    static DevOnce lds_once;
+    TSIM_MAX_LDS(lds_once, kern, lds);
+    if (K % LR_BK != 0 || K < 2 * LR_BK) return fail(TSIM_EUNSUPPORTED, "ln_rows_gemm: K=%d", K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, X, Wimg32, bias, res, gamma, beta, eps, out, M, K);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
 template <int EPI>
 static int gemm_plain(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, bf16_t *out, int M, int N,
                       int K, hipStream_t st) {
@@ -1856,7 +2074,7 @@ static int gemm_plain(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const 
 
 static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, const bf16_t *res,
                        const float *gamma, const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf,
-                       hipStream_t st, const bf16_t *Wimg = nullptr) {
+                       hipStream_t st, const bf16_t *Wimg = nullptr, const bf16_t *Wimg32 = nullptr) {
     static int use_img = -1;
     if (use_img < 0) { const char *e = getenv("TSIM_LN_WIMG"); use_img = e ? atoi(e) : 1; }
     if (!use_img) Wimg = nullptr;
@@ -1878,17 +2096,43 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
             if (split < 0) { const char *e = getenv("TSIM_LN_TAIL"); split = e ? atoi(e) : 1; }
             // (64-token tiles measured slower: 64 x 384 x 32-k with two workgroups per CU 2.96 ms per forward, 64 x 384 x 64-k 3.08,
             // against 2.74: the W tile is re-staged for half as many tokens)
+            // 256-token tiles, one 32-token row block per wave (ln_rows_gemm_kernel), for whole rounds of 256 tiles and for a last
+            // round that is at least half full; everything else — and every small batch — goes through the 128- / 32-token
+            // forms below.  All forms give a row the same bits (bit-wise large-vs-small-batch test).
+            static int rows256 = -1;
+            if (rows256 < 0) { const char *e = getenv("TSIM_LN_ROWS256"); rows256 = e ? atoi(e) : 1; }
+            bool after_rows = false;   // the rest below is the remainder of a ln_rows launch: a true tail
+            if (rows256 && Wimg32) {
+                const int t256 = M / 256;
+                const int use = (t256 % 256) >= 128 ? t256 : (t256 / 256) * 256;
+                if (use > 0) {
+                    int rc = ln_rows_gemm(X, Wimg32, bias, res, gamma, beta, eps, out, use, use * 256, K, st);
+                    const int m1 = use * 256;
+                    if (rc || m1 == M) return rc;
+                    X += (int64_t)m1 * K; res += (int64_t)m1 * N; out += (int64_t)m1 * N; M -= m1;
+                    after_rows = true;
+                }
+            }
             const int mt = (M + 127) / 128, full = (mt / 256) * 256, rem = mt - full;
             // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep
             // path issues a k-tile's DMA pieces in one burst ahead of the MFMAs instead of behind each k-step's)
             auto main_launch = [&](int rows) {
                 return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st, Wimg);
             };
-            if (split && full > 0 && rem > 0 && rem <= 96) {
+            if (split && rem > 0 && rem <= 96 && (full > 0 || after_rows)) {
                 const int m_main = full * 128;
-                int rc = main_launch(m_main);
-                if (rc) return rc;
+                if (full > 0) {
+                    int rc = main_launch(m_main);
+                    if (rc) return rc;
+                }
                 // (a three-slot ring for the remainder launch measured no different: 2.744-2.751 vs 2.751-2.752 ms per forward)
+                // TSIM_LN_TAIL_BM: token rows per workgroup of the remainder launch (32: four waves, 64: eight waves = 7 instead of
+                // 13 DMA pieces per wave and k-tile)
+                static int tail_bm = -1;
+                if (tail_bm < 0) { const char *e = getenv("TSIM_LN_TAIL_BM"); tail_bm = e ? atoi(e) : 64; }
+                if (tail_bm == 64)
+                    return launch_gemm<64, 384, 64, 2, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
+                                                                      gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg);
                 return launch_gemm<32, 384, 64, 1, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
                                                                   gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg);
             }
@@ -1979,6 +2223,12 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
                                reinterpret_cast<const uint4 *>(d.wo), reinterpret_cast<uint4 *>(d.lo), 384, 64, H);
             hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * F / 8 + 255) / 256)), dim3(256), 0, 0,
                                reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l2), 384, 64, F);
+            if ((rc = dev_alloc(e, (size_t)H * H * 2, (void **)&d.lo32))) return bail(rc);
+            if ((rc = dev_alloc(e, (size_t)H * F * 2, (void **)&d.l232))) return bail(rc);
+            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * H / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.wo), reinterpret_cast<uint4 *>(d.lo32), 384, 32, H);
+            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * F / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l232), 384, 32, F);
             if (hipGetLastError() != hipSuccess) return bail(fail(TSIM_EHIP, "LayerNorm GEMM weight packing failed"));
         }
         if (!mx && H == 384 && F % 64 == 0 && F <= 4096) {   // fused FFN (ffn_fused_kernel): both matrices as LDS images
@@ -2132,7 +2382,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 if ((rc = res_ln_rows(e->ybuf, e->x1, L.g2, L.be2, c.ln_eps, e->x0, e->aq, e->as, T, H, st))) return rc;
                 continue;
             }
-            if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st, L.lo))) return rc;
+            if ((rc = gemm_res_ln(e->ctx, L.wo, L.po, L.bo, e->x0, L.g1, L.be1, c.ln_eps, e->x1, T, H, H, e->ybuf, st, L.lo, L.lo32))) return rc;
             static int fused = -1;
             // OFF by default: at the bench shape (67 k tokens = 525 blocks of 128 on 256 CUs: three rounds) the fused kernel
             // takes 256 us per layer against 245 us for FFN1 + FFN2 + tail (profiles/README.md, round 2); kept for shapes that
@@ -2143,7 +2393,7 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 continue;
             }
             if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, nullptr, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st, L.l2))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st, L.l2, L.l232))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

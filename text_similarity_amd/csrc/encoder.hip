@@ -1405,9 +1405,20 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const bf16_t *__restrict
 // tiles in flight across the barrier), fragment reads rolling four ahead with counted lgkmcnt, 24 MFMAs per wave and tile.
 // Per k-tile: 40 KiB staged (640 LDS cycles) + 208 KiB read (832) for 1 536 MFMA cycles per SIMD.
 // =====================================================================================================
-constexpr int LR_BK = 32, LR_NST = 3, LR_WBYTES = 384 * LR_BK * 2;
+// NW = waves = 32-token row blocks per workgroup, NST = ring slots.  <8, 3>: the main form (256 tokens, 120 KiB).  <2, 5>: the
+// REMAINDER form — 64 tokens per workgroup, and since such a launch has far fewer workgroups than CUs, a five-slot ring (140 KiB)
+// that keeps three tiles in flight: a remainder's cost is its k loop's LATENCY (k-tiles x time per tile, whatever the token
+// count), and an LDS-DMA tile takes ~1.1 us from issue to landing.  Every wave runs the same instruction stream on its rows in
+// both forms: same bits.
+constexpr int LR_BK = 32, LR_WBYTES = 384 * LR_BK * 2;
 
-template <int NW>
+// STAG (stagger): an LDS-DMA instruction costs the ISSUING wave 60-185 cycles (five pieces per wave and tile: ~650 cycles
+// against 768 of MFMA), and when all eight waves issue right behind the barrier no MFMA runs anywhere on the CU meanwhile
+// (measured: 2 700 cycles per tile for 1 536 of matrix work).  With STAG the second half of the waves — the SIMD partners of
+// the first half — issue their pieces AFTER their MFMAs: on every SIMD one wave feeds the matrix pipe while the other queues
+// at the address path.  Their tile then has one tile period less to land, hence one ring slot more (four: exactly 160 KiB).
+// Measured EQUAL to the plain three-slot form (profiles/README.md, round 3) and left as an opt-in (TSIM_LN_ROWS_STAG=1).
+template <int NW, int LR_NST, bool STAG = false>
 __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wimg,
                                                                const float *__restrict__ bias, const bf16_t *__restrict__ res,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -1468,15 +1479,17 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
             wo[sk][par] = lbase + XBYTES + (r >> 2) * 256 + ((ch ^ (((par << 3) + (r >> 2)) & 15)) << 4);
     }
 
-    issue(0, 0);
-    issue(1, 1);
+    static_assert(LR_NST >= 3 && (LR_NST - 2) * PPW <= 63, "ring depth");
 #pragma unroll
-    for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(acc[t]));   // retire the bias loads here (and with them tiles 0 and 1)
+    for (int i = 0; i < LR_NST - 1; ++i) issue(i, i);
+#pragma unroll
+    for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(acc[t]));   // retire the bias loads here (and with them the first tiles)
     auto do_tile = [&](int kt, auto stc) __attribute__((always_inline)) {
         constexpr int stage = decltype(stc)::value;
-        wait_vmcnt<PPW>();                 // my pieces of tile kt (those of kt + 1 stay in flight)
+        wait_vmcnt<(LR_NST - 2) * PPW>();  // my pieces of tile kt (those of kt + 1 .. kt + NST - 2 stay in flight)
         __builtin_amdgcn_s_barrier();      // everyone's landed; everyone is past tile kt - 1
-        issue(kt + 2, (stage + 2) % LR_NST);
+        const bool late = STAG && wave >= NW / 2;
+        if (!late) issue(kt + LR_NST - 1, (stage + LR_NST - 1) % LR_NST);
         constexpr int PF = 4, NRD = 24;
         lds_u32x4 bfr[2], fr[PF + 1];
         const uint32_t so = stage * STAGE;
@@ -1498,15 +1511,20 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
             acc[n % 12] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]),
                                                                    __builtin_bit_cast(bf16x8, bfr[n / 12]), acc[n % 12], 0, 0, 0);
         });
+        if (late) {
+#pragma unroll
+            for (int t = 0; t < 12; ++t) asm volatile("" : "+v"(acc[t]));   // keep the issue behind the MFMA stream
+            issue(kt + LR_NST - 1, (stage + LR_NST - 1) % LR_NST);
+        }
     };
     int kt = 0;
-    for (; kt + 3 <= nk; kt += 3) {
-        do_tile(kt, std::integral_constant<int, 0>{});
-        do_tile(kt + 1, std::integral_constant<int, 1>{});
-        do_tile(kt + 2, std::integral_constant<int, 2>{});
-    }
-    if (kt < nk) do_tile(kt, std::integral_constant<int, 0>{});
-    if (kt + 1 < nk) do_tile(kt + 1, std::integral_constant<int, 1>{});
+    for (; kt + LR_NST <= nk; kt += LR_NST)
+        ff_static_for(std::make_integer_sequence<int, LR_NST>{}, [&](auto sc) __attribute__((always_inline)) {
+            do_tile(kt + decltype(sc)::value, sc);
+        });
+    ff_static_for(std::make_integer_sequence<int, LR_NST - 1>{}, [&](auto sc) __attribute__((always_inline)) {
+        if (kt + decltype(sc)::value < nk) do_tile(kt + decltype(sc)::value, sc);
+    });
     wait_vmcnt<0>();   // past-the-end tiles must not outlive the workgroup
 
     // ---------------------------------------------------------------- epilogue: + residual, LayerNorm, store (wave-local)
@@ -2045,15 +2063,18 @@ static int ffn_fused(const bf16_t *X, const bf16_t *W1img, const bf16_t *W2img, 
     return TSIM_OK;
 }
 
-// whole 256-token tiles of a LayerNorm GEMM of width 384 (tiles * 256 <= M rows)
+// LayerNorm GEMM of width 384 over rows [0, M) in workgroups of NW * 32 token rows (the last one may be partial)
+template <int NW, int NST, bool STAG = false>
 static int ln_rows_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias, const bf16_t *res, const float *gamma,
-                        const float *beta, float eps, bf16_t *out, int tiles, int M, int K, hipStream_t st) {
-    constexpr int lds = LR_NST * (8 * 32 * LR_BK * 2 + LR_WBYTES);   // 120 KiB
-    auto kern = ln_rows_gemm_kernel<8>;
+                        const float *beta, float eps, bf16_t *out, int M, int K, hipStream_t st) {
+    constexpr int lds = NST * (NW * 32 * LR_BK * 2 + LR_WBYTES);   // <8, 3>: 120 KiB, <2, 5>: 140 KiB
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = ln_rows_gemm_kernel<NW, NST, STAG>;
     static DevOnce lds_once;
     TSIM_MAX_LDS(lds_once, kern, lds);
-    if (K % LR_BK != 0 || K < 2 * LR_BK) return fail(TSIM_EUNSUPPORTED, "ln_rows_gemm: K=%d", K);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, st, X, Wimg32, bias, res, gamma, beta, eps, out, M, K);
+    if (K % LR_BK != 0 || K < NST * LR_BK) return fail(TSIM_EUNSUPPORTED, "ln_rows_gemm: K=%d", K);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((M + NW * 32 - 1) / (NW * 32))), dim3(NW * 64), lds, st, X, Wimg32, bias, res, gamma,
+                       beta, eps, out, M, K);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -2106,12 +2127,21 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 const int t256 = M / 256;
                 const int use = (t256 % 256) >= 128 ? t256 : (t256 / 256) * 256;
                 if (use > 0) {
-                    int rc = ln_rows_gemm(X, Wimg32, bias, res, gamma, beta, eps, out, use, use * 256, K, st);
+                    static int stag = -1;
+                    if (stag < 0) { const char *e = getenv("TSIM_LN_ROWS_STAG"); stag = e ? atoi(e) : 0; }   // measured equal (68.5 vs 66-68 us per launch): off
+                    int rc = stag ? ln_rows_gemm<8, 4, true>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st)
+                                  : ln_rows_gemm<8, 3>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st);
                     const int m1 = use * 256;
                     if (rc || m1 == M) return rc;
                     X += (int64_t)m1 * K; res += (int64_t)m1 * N; out += (int64_t)m1 * N; M -= m1;
                     after_rows = true;
                 }
+                // a remainder of at most 128 workgroups of 64 rows: the deep-ring form (TSIM_LN_ROWS_TAIL=0: the 64- / 32-token
+                // tiles of gemm_bf16_kernel below)
+                static int rows_tail = -1;
+                if (rows_tail < 0) { const char *e = getenv("TSIM_LN_ROWS_TAIL"); rows_tail = e ? atoi(e) : 0; }
+                if (rows_tail && after_rows && M <= 128 * 64 && K >= 5 * LR_BK)
+                    return ln_rows_gemm<2, 5>(X, Wimg32, bias, res, gamma, beta, eps, out, M, K, st);
             }
             const int mt = (M + 127) / 128, full = (mt / 256) * 256, rem = mt - full;
             // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep

@@ -201,14 +201,17 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
         }
     };
     // Lists are sorted and padded with (-inf, -1): a lane walks whole lists (list = lane, lane+64, ...).  With pre-pass
-    // thresholds most lists hold 0-3 entries, so the first four entries (16 + 16 B) of EIGHT lists are requested together —
-    // one memory round trip per 512 lists instead of two per list (the walk was a chain of dependent loads: 16 round trips
-    // at Q = 256, where P2 = 512) — and only a list that is full that far is walked on.
-    for (int l0 = lane; l0 < P2; l0 += 512) {
-        int4 iv[8];
-        float4 sv[8];
+    // thresholds most lists hold 0-3 entries, so the first four entries (16 + 16 B) of FOUR lists are requested together —
+    // one memory round trip per 256 lists instead of two per list (the walk was a chain of dependent loads: 16 round trips
+    // at Q = 256, where P2 = 512) — and only a list that is full that far is walked on.  (Eight lists at a time cost 32 more
+    // registers: 160 instead of <= 128, one wave per SIMD less, and the kernel — pure latency — ran 152 us instead of 80 at
+    // Q = 4096.)
+    constexpr int LB = 4;
+    for (int l0 = lane; l0 < P2; l0 += 64 * LB) {
+        int4 iv[LB];
+        float4 sv[LB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < LB; ++u) {
             const int l = l0 + 64 * u;
             iv[u] = make_int4(-1, -1, -1, -1);
             sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -218,7 +221,7 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < LB; ++u) {
             if (iv[u].x < 0) continue;
             consider(sv[u].x, iv[u].x);
             consider(sv[u].y, iv[u].y);
@@ -323,7 +326,13 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
 
     float my_s;  // lane t < KL ends up holding the t-th selected candidate
     int my_i;
+#if defined(TSIM_FIN_DIAG) && (TSIM_FIN_DIAG & 1)   // TIMING-ONLY (wrong results): no selection, the first list's entries
+    my_s = lane < KL ? ps[lane] : -INFINITY;
+    my_i = lane < KL ? pi[lane] : -1;
+    if (my_i < 0 && lane < KL) { my_i = (int)((q * 977 + lane * 131) % N); my_s = 0.f; }
+#else
     select_kl_best<KL>(ps, pi, P2, lane, my_s, my_i);
+#endif
     const int nvalid = __popcll(__ballot(my_i >= 0));   // candidates sit in lanes 0 .. nvalid-1
 
     // 2. exact re-score: the wave works on one candidate at a time (coalesced row reads)
@@ -336,7 +345,12 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + u < nvalid ? t0 + u : t0;   // past the end: repeat a valid one, result unused
             const int ci = __shfl(my_i, t, 64);
+#if defined(TSIM_FIN_DIAG) && (TSIM_FIN_DIAG & 2)   // TIMING-ONLY (wrong results): no exact re-score
+            const float sc = __shfl(my_s, t, 64);
+            (void)ci;
+#else
             const float sc = exact_score<T, COS>(eqr, xc + (int64_t)ci * ldc, d, lane);
+#endif
             if (lane == t0 + u) cs = sc;
         }
     }

@@ -76,6 +76,9 @@ def main() -> None:
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--cmd", default="python bench.py --steps 10 --warmup 2 --no-cpu-baseline")
     ap.add_argument("--searches", type=int, default=4, help="searches (steps + warm-up) of the PMC command")
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--preset", default="all-MiniLM-L6-v2")
+    ap.add_argument("--cmd-pmc", default="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify")
     ap.add_argument("--launches-per-search", type=int, default=2,
                     help="main-pass launches of one tsim_cosine_topk call (2 since round 2: phase A + phase B)")
     a = ap.parse_args()
@@ -124,6 +127,28 @@ def main() -> None:
                                   "WRITE_SIZE exact",
                     "passes": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace", "rocprofv3 --pmc WRITE_SIZE --kernel-trace"],
                 }
+    # encoder: HBM bytes per layer = sum over the layer's kernels (projections, attention, LayerNorm GEMMs and their remainder
+    # launches) of FETCH x 2 + WRITE, over all forwards of the PMC command, divided by forwards x layers
+    if a.fetch and a.write:
+        layer_kernels = ("gemm_xres", "attention_kernel", "ln_rows_gemm", "gemm_bf16_kernel", "ffn_fused", "gemm_pp", "res_ln_rows")
+        tot_f = sum(v * n for k, (v, n) in fe.items() if any(t in k for t in layer_kernels))
+        tot_w = sum(v * n for k, (v, n) in wr.items() if any(t in k for t in layer_kernels))
+        per_layer = (2 * tot_f + tot_w) * 1024 / (a.searches * a.layers)
+        lines += ["", f"encoder: FETCH x 2 + WRITE over the layer kernels of {a.searches} forwards x {a.layers} layers = "
+                      f"{per_layer / 1e6:.1f} MB per layer"]
+        for k in sorted(fe):
+            if any(t in k for t in layer_kernels):
+                fk, n = fe[k]
+                wk = wr.get(k, (0.0, 0))[0]
+                lines.append(f"   per launch {(2 * fk + wk) * 1024 / 1e6:8.1f} MB  x {n:3d}  {k[:100]}")
+        with open(os.path.join(out_dir, f"{a.round}_encoder_traffic.json"), "w") as fh:
+            json.dump({"round": int(a.round.lstrip("r")), "gpu": "MI355X (gfx950)", "command": a.cmd_pmc,
+                       "workload": {"preset": a.preset, "sentences_per_step": a.queries},
+                       "hbm_bytes_per_layer": int(per_layer), "layers": a.layers, "forwards": a.searches,
+                       "definition": "sum over the layer's kernels (QKV / FFN1 projections, attention, LayerNorm GEMMs with their "
+                                     "remainder launches) of FETCH_SIZE x 2 + WRITE_SIZE, all forwards of the command, / (forwards x layers)",
+                       "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE exact"}, fh, indent=1)
+            fh.write("\n")
     with open(os.path.join(out_dir, f"{a.round}_summary.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     if traffic is not None:

@@ -172,3 +172,36 @@ class SemanticSearchPipeline(SearchPipeline):
     def num_indexed(self):
         """current number of indexed embeddings"""
         return self.index.num_live()
+
+
+class APISearchPipeline(SemanticSearchPipeline):
+    """/root/reference/src/pipeline/search_pipeline.py:178-226: the serving variant of ``SemanticSearchPipeline`` whose
+    query encoder is an ``onnxruntime.InferenceSession`` over ``params.model_path``.  Here the "session" is the native
+    MI355X encoder the pipeline was built with (there is no ONNX runtime on this path): same constructor
+    (``params, max_n_results, *args, inference_mode=True, session_options=None``), same ``__call__`` and the same
+    ``encode_corpus(documents)`` contract — a list of per-sentence embedding rows in the caller's order (the reference
+    sorts by length for batching and un-sorts, :200-226; ``encode_text`` does the same on the device).  The reference's loop
+    reshapes every batch to ONE row before ``session.run`` (:217-220), which only works for batches of one sentence; the
+    intended per-sentence embeddings are what is returned."""
+
+    def __init__(self, params, max_n_results: int, *args, inference_mode: bool = True, session_options=None, **kwargs):
+        # the reference forwards *args to SemanticSearchPipeline(index_path, params, model): its callers pass params a second
+        # time there; (index_path, model) alone is accepted as well
+        args = list(args)
+        if len(args) == 2 and "model" not in kwargs:
+            args.insert(1, params)
+        super().__init__(*args, **kwargs)
+        self.params = params
+        self.inference_mode = inference_mode
+        self.sess_options = session_options
+        self.max_n_results = max_n_results
+        self.session = self.model          # what runs the encoder forward
+
+    def __call__(self, queries, max_num_results: Optional[int] = None):
+        return self._search(queries, self.max_n_results if max_num_results is None else max_num_results)
+
+    def encode_corpus(self, documents, convert_to_numpy: bool = False, return_embeddings: bool = False):
+        if not isinstance(documents, list):
+            return documents
+        emb = self.model.encode_text(documents, output_np=False)
+        return emb

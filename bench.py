@@ -279,7 +279,7 @@ def main():
     # ... and four of its rows against the oracle's restatement of the reference search (F.cosine_similarity of the float32
     # embeddings + topk), bit for bit, at the full bench shape (single GPU: the oracle needs the whole corpus on the host)
     verified = None
-    if world == 1 and rank == 0 and not args.no_verify:
+    if world == 1 and rank == 0 and not args.no_verify and n_local <= 2_000_000:   # (the oracle scans the corpus on the host)
         from oracle import search_ref
         sel = [0, Q // 3, (2 * Q) // 3, Q - 1]
         rs, ri = search_ref.cosine_topk_f32(emb_last[sel].cpu().numpy(), corpus_f32.cpu().numpy(), k)

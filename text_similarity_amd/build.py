@@ -82,7 +82,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), only=None) 
                 name = ln.split("Function Name:")[1].split("[")[0].strip()
             elif "ScratchSize [bytes/lane]:" in ln and name:
                 n = int(ln.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
-                if n > 0 and any(k in name for k in HOT_KERNELS):
+                # (a tagged variant build may opt out: TSIM_ALLOW_SCRATCH=1 — in-kernel stamps cost a few registers)
+                if n > 0 and any(k in name for k in HOT_KERNELS) and not (TAG and os.environ.get("TSIM_ALLOW_SCRATCH")):
                     try:
                         os.remove(obj)
                     except OSError:

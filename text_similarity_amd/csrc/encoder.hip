@@ -28,6 +28,22 @@
 namespace tsim {
 
 // =====================================================================================================
+// BLOCK-PACKED activation layout (round 3) for the wide intermediates of the hidden-384 path, qkv [T, 3H] and h1 [T, F]:
+//     element (token t, feature f)  ->  ((t >> 5) * (W / 8) + (f >> 3)) * 256 + (t & 31) * 8 + (f & 7)      (W = row width)
+// i.e. per block of 32 tokens and group of 8 features one contiguous 512-byte run of [token][8 features].  Why: a wave of the
+// projection kernels owns 32 tokens x 32 features and stores 16 bytes per lane; in the row-major layout one store instruction
+// touches 32 rows x 32 B, and such a store costs its wave ~400 cycles of issue (tools/microbench/mfma_loop: two of them per
+// step 2 598 cycles against 1 780 without and 1 913 with two CONTIGUOUS 1-KiB stores; in-kernel stamps 650-750 per step).  In
+// the packed layout the same instruction writes 1 KiB of contiguous memory.  The readers gain too: attention's q / k / v loads
+// (16 B per lane of 32 consecutive tokens: two runs instead of 32 pieces) and the LDS-DMA pieces of the FFN2 operand (256-byte
+// runs instead of 64-byte ones).  A block of 32 tokens occupies 32 * W elements in both layouts, so block-aligned row offsets
+// are the same.  Token counts are padded to 128 (+128) rows by the encoder's buffers.
+// =====================================================================================================
+__device__ __forceinline__ int64_t packed_off(int64_t t, int f, int W) {   // element offset of (t, f), f a multiple of 8 here
+    return ((t >> 5) * (W >> 3) + (f >> 3)) * 256 + (t & 31) * 8 + (f & 7);
+}
+
+// =====================================================================================================
 // embeddings: x[t] = LayerNorm(word[id] + pos[pos_id] (+ type[0]))        one wave per token, fp32 math
 // HBM-bound: reads 2-3 rows of H floats, writes H bf16.
 // =====================================================================================================
@@ -113,7 +129,8 @@ template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int NST = 2
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
     const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
     const bf16_t *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles, const bf16_t *__restrict__ Wimg) {
+    bf16_t *__restrict__ out, int M, int N, int K, int mtiles, int ntiles, const bf16_t *__restrict__ Wimg, int xpacked) {
+    // xpacked: X is in the block-packed layout (packed_off; BM is a multiple of 32, so a tile starts on a block)
     // Wimg (optional, BN == N): W re-laid at load time as the LDS images of its k-tiles (pack_gemm_w_kernel), so that every
     // DMA piece of the W operand is 1 KiB of CONTIGUOUS memory.  From row-major W a piece gathers 8 rows x 128 B, and that
     // shape streams from L2 at half the rate (tools/microbench/dma_stream: 60 vs 115-128 GB/s per CU); W is 3/4 of the bytes
@@ -155,14 +172,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void gemm_bf16_kernel(
         const int sr = sl >> 4, chp = sl & 15;
         const int ch = chp ^ (sr & 15);
         const int row = sr * RPS + ch / CPR, c = ch % CPR;
-        src_off[i] = row * K * 2 + c * 16;
+        src_off[i] = (isx && xpacked) ? (row >> 5) * K * 64 + (row & 31) * 16 + c * 512 : row * K * 2 + c * 16;
     }
+    const int xkstride = xpacked ? (BK / 8) * 512 : BK * 2;   // bytes per k-tile along a row of X
     const char *xbase = reinterpret_cast<const char *>(X + (int64_t)m0 * K);
     const char *wbase = reinterpret_cast<const char *>(W + (int64_t)n0 * K);
     const char *wimg = reinterpret_cast<const char *>(Wimg);
     // source of piece p (this wave's i-th) for k-tile kt
     auto piece_src = [&](int i, int p, int kt) __attribute__((always_inline)) -> const char * {
-        if (p < XPIECES) return xbase + src_off[i] + kt * (BK * 2);
+        if (p < XPIECES) return xbase + src_off[i] + kt * xkstride;
         if (wimg) return wimg + (int64_t)kt * W_BYTES + (p - XPIECES) * 1024 + lane * 16;
         return wbase + src_off[i] + kt * (BK * 2);
     };
@@ -537,7 +555,10 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 // [5] activation reloads, [6] items.
 __device__ unsigned long long g_xr_stamps[8];
 #define XR_T() __builtin_amdgcn_s_memtime()
-#define XR_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&g_xr_stamps[i], (unsigned long long)(v)); } while (0)
+#ifndef TSIM_XR_STAMP_TID
+#define TSIM_XR_STAMP_TID 0   // 256: wave 4, the SIMD partner of wave 0
+#endif
+#define XR_ACC(i, v) do { if (threadIdx.x == TSIM_XR_STAMP_TID) atomicAdd(&g_xr_stamps[i], (unsigned long long)(v)); } while (0)
 #else
 #define XR_T() 0ull
 #define XR_ACC(i, v) do { } while (0)
@@ -804,7 +825,7 @@ __device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, 
 // =====================================================================================================
 constexpr int X2_BN = 96, X2_BK = 128, X2_NSTAGE = 3, X2_KG = 3, X2_NSUB = 3;
 
-template <int EPI>
+template <int EPI, bool PK>   // PK: the output goes out in the block-packed layout (see packed_off)
 __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
                                                          const float *__restrict__ bias, bf16_t *__restrict__ out,
                                                          int M, int N, int items_total) {
@@ -863,27 +884,34 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
 
     // epilogue of ONE finished sub-tile whose 16 registers have been packed into pk[8] (pk[2gq], pk[2gq+1] = the lane's four
     // features 8gq + 4h .. +3 of group gq): swap half-waves so that every lane owns 8 contiguous features, two 16-byte stores
-    auto store_sub = [&](const uint32_t (&pk)[8], int mrow0, int ncol) __attribute__((always_inline)) -> int {
-        const int64_t m = mrow0 + r;
+    // EARLY STORES (round 3).  Stamps (tools/x2_stamps.py): the two 16-byte stores of a sub-tile, issued between a step's MFMA
+    // stream and the next barrier, cost their wave 650-750 cycles per step (a store instruction touches 32 rows x 32 B and is
+    // issue-bound), during which it feeds nothing to the matrix pipe — and both partners of a SIMD sit in that segment or at the
+    // barrier for ~30 % of a step.  Here the shadow epilogue runs at double density over the first four k-steps (all of pk[] is
+    // ready after k-step 3) and the two stores go out INSIDE the stream, behind k-steps 4 and 6: while a wave queues at the
+    // address path its partner has the matrix pipe.  Same values, same addresses; only the issue position moves.
+#ifndef TSIM_X2_EARLY_STORE
+#define TSIM_X2_EARLY_STORE 0   // measured EQUAL to stores at the end of the step (2.61-2.62 ms per forward either way; the
+#endif                          // micro-benchmark agrees: 2 480 vs 2 598 cycles per step): what costs is the store's PATTERN
+    // (the store is inline asm in the SGPR-base + 32-bit-offset form: inside the stream there is no room for a 64-bit address
+    // per store; the output is < 4 GiB, checked by the launcher.  All vmcnt bookkeeping of this kernel is manual anyway.)
+    uint32_t old_rowoff = 0;   // byte offset of this lane's 16-byte column group in its token row of the PREVIOUS item's block
+    const uint64_t out_base = (uint64_t)(uintptr_t)out;
+    auto store_half = [&](const uint32_t (&pk)[8], int mrow0, int ncol, auto gqc) __attribute__((always_inline)) {
+        constexpr int gq = decltype(gqc)::value;
         const bool full = mrow0 + 32 <= M;    // wave-uniform
-#pragma unroll
-        for (int gq = 0; gq < 4; gq += 2) {
-            uint32_t a0 = pk[2 * gq], a1 = pk[2 * gq + 1], b0 = pk[2 * gq + 2], b1 = pk[2 * gq + 3];
-            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            const uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-            bf16_t *dst = out + m * N + ncol + 8 * gq + 8 * h;
-#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)   // TIMING-ONLY: no output stores (one lane keeps the value alive)
-            if (o.x == 0x12345678u && m < 0) *reinterpret_cast<uint4 *>(dst) = o;
+        uint32_t a0 = pk[2 * gq], a1 = pk[2 * gq + 1], b0 = pk[2 * gq + 2], b1 = pk[2 * gq + 3];
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        const uint32_t voff = old_rowoff + (uint32_t)(ncol + 8 * gq) * (PK ? 64u : 2u);
+        const uint64_t ob = out_base;   // (an asm operand alone does not make a generic lambda capture the variable)
+#if !(defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1))   // (bit 1: TIMING-ONLY, no output stores)
+        if (full || mrow0 + r < M)
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(o), "s"(ob) : "memory");
 #else
-            if (full) *reinterpret_cast<uint4 *>(dst) = o;
-            else if (m < M) *reinterpret_cast<uint4 *>(dst) = o;
+        asm volatile("" ::"v"(voff), "v"(o));
 #endif
-        }
-#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)
-        return 0;
-#endif
-        return full ? 2 : -1;
     };
     auto finish2 = [&](float y0, float y1) __attribute__((always_inline)) -> uint32_t {
 #if !(defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 2))   // (bit 2: TIMING-ONLY, no activation function)
@@ -895,6 +923,7 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
 
     issue(0, 0);
     issue(1, 1);
+    [[maybe_unused]] unsigned x2_n = 0, x2_w = 0, x2_c = 0, x2_e = 0;   // (diagnostic build only; 32-bit sums: a workgroup runs < 2^32 cycles)
     auto run_item = [&](f32x16 (&cur)[X2_NSUB], f32x16 (&old)[X2_NSUB], int item, auto with_old) __attribute__((always_inline)) {
         constexpr bool OLD = decltype(with_old)::value;
         if (item / ntiles != cur_mb) {                        // wave-uniform: new token block -> reload fragments
@@ -922,12 +951,24 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
 #pragma unroll
         for (int g = 0; g < X2_KG; ++g) {
             const int stage = st % X2_NSTAGE;
+            [[maybe_unused]] const unsigned long long xs0 = XR_T();
             // ring wait: the tile of this step was issued two steps ago; the stores of the last two steps are younger than it
+            if constexpr (TSIM_X2_EARLY_STORE) {
+                // issue order inside a step: piece a (k-step 1), piece b (3), store 1 (4), piece c (5), store 2 (6).  Younger than
+                // the pieces of step st-2: its store 2, and everything of step st-1.
+                const int extra = (young1 >= 0 && young2 >= 0) ? young1 + (young2 >> 1) : 0;   // 0 (or unknown: drain), 1, 2, 3
+                if (extra == 3) wait_vmcnt<PPW + 3>();
+                else if (extra == 2) wait_vmcnt<PPW + 2>();
+                else if (extra == 1) wait_vmcnt<PPW + 1>();
+                else wait_vmcnt<PPW>();
+            } else {
             if (young1 == 0 && young2 == 0) wait_vmcnt<PPW>();
             else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 2) wait_vmcnt<PPW + 2>();
             else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 4) wait_vmcnt<PPW + 4>();
             else wait_vmcnt<PPW>();                           // unknown store count: drain (always safe)
+            }
             __builtin_amdgcn_s_barrier();
+            [[maybe_unused]] const unsigned long long xs1 = XR_T();
             // Right behind the barrier all eight waves have LDS-DMA to issue and queue at the CU's one address path while the
             // matrix pipe idles; the tile is not needed for two steps, so its three pieces are dropped between the k-steps'
             // MFMAs instead (TSIM_X2_SPREAD=0: all three at the head of the step).
@@ -966,7 +1007,15 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                     if constexpr (i == X2_NSUB - 1) {
                         if constexpr (TSIM_X2_SPREAD && (ks == 1 || ks == 3 || ks == 5))
                             issue_pieces(st + 2, (stage + 2) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
-                        if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
+                        if constexpr (OLD && !TSIM_X2_EARLY_STORE) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
+                        if constexpr (OLD && TSIM_X2_EARLY_STORE) {
+                            if constexpr (ks < 4) {
+                                pk[2 * ks] = finish2(old[g][4 * ks], old[g][4 * ks + 1]);
+                                pk[2 * ks + 1] = finish2(old[g][4 * ks + 2], old[g][4 * ks + 3]);
+                            }
+                            if constexpr (ks == 4) store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 0>{});
+                            if constexpr (ks == 6) store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 2>{});
+                        }
                     }
                 });
             }
@@ -985,13 +1034,39 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             }
 #endif
             (void)ws;
+#ifdef TSIM_PP_STAMPS
+#pragma unroll
+            for (int i = 0; i < X2_NSUB; ++i) asm volatile("" : "+v"(cur[i]));
+#endif
+            [[maybe_unused]] const unsigned long long xs2 = XR_T();
             young2 = young1;
             young1 = 0;
-            if constexpr (OLD) young1 = store_sub(pk, old_m0, old_n0 + g * 32);
+            if constexpr (OLD) {
+                if constexpr (TSIM_X2_EARLY_STORE) {
+#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)
+                    young1 = 0;
+#else
+                    young1 = old_m0 + 32 <= M ? 2 : -1;      // both stores of this step were issued for certain / unknown
+#endif
+                } else {
+                    store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 0>{});
+                    store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 2>{});
+#if defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1)
+                    young1 = 0;
+#else
+                    young1 = old_m0 + 32 <= M ? 2 : -1;
+#endif
+                }
+            }
             ++st;
+#ifdef TSIM_PP_STAMPS
+            { const unsigned long long xs3 = XR_T(); x2_n += 1; x2_w += (unsigned)(xs1 - xs0); x2_c += (unsigned)(xs2 - xs1); x2_e += (unsigned)(xs3 - xs2); }
+#endif
         }
         old_m0 = m0;
         old_n0 = n0;
+        old_rowoff = PK ? (uint32_t)(m0 >> 5) * (uint32_t)(N * 64) + 16u * r + 512u * h     // m0 is a multiple of 32
+                        : (uint32_t)(m0 + r) * (uint32_t)(N * 2) + 16u * h;
     };
     int item = it0;
     run_item(accA, accB, item++, std::false_type{});
@@ -1009,10 +1084,12 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             uint32_t pk[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) pk[ks] = finish2(acc[g][2 * ks], acc[g][2 * ks + 1]);
-            (void)store_sub(pk, old_m0, old_n0 + g * 32);
+            store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 0>{});
+            store_half(pk, old_m0, old_n0 + g * 32, std::integral_constant<int, 2>{});
         }
     };
     if (lastA) flush(accA); else flush(accB);
+    XR_ACC(0, x2_n); XR_ACC(1, x2_w); XR_ACC(3, x2_c); XR_ACC(4, x2_e); XR_ACC(6, x2_n / 3);
 }
 
 // =====================================================================================================
@@ -1423,7 +1500,8 @@ template <int NW, int LR_NST, bool STAG = false>
 __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wimg,
                                                                const float *__restrict__ bias, const bf16_t *__restrict__ res,
                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                               float eps, bf16_t *__restrict__ out, int M, int K) {
+                                                               float eps, bf16_t *__restrict__ out, int M, int K, int xpacked) {
+    // xpacked: X is in the block-packed layout (packed_off): FFN2's operand h1
     constexpr int N = 384, XBYTES = NW * 32 * LR_BK * 2, STAGE = XBYTES + LR_WBYTES;
     constexpr int XP = XBYTES / 1024, PIECES = STAGE / 1024, PPW = PIECES / NW;   // pieces 0..XP-1: X, the rest: W
     static_assert(PIECES % NW == 0 && XP == 2 * NW, "every wave issues two X pieces and PPW - 2 W pieces per k-tile");
@@ -1454,14 +1532,16 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
         const int sr = sl >> 4, ch = (sl & 15) ^ (sr & 15);
         const int row = sr * 4 + (ch >> 2);
         const int64_t m = m0 + row < M ? m0 + row : M - 1;     // rows past M repeat the last one (never stored)
-        xsrc[i] = reinterpret_cast<const char *>(X) + m * K * 2 + (ch & 3) * 16;
+        xsrc[i] = xpacked ? reinterpret_cast<const char *>(X + packed_off(m, (ch & 3) * 8, K))
+                          : reinterpret_cast<const char *>(X) + m * K * 2 + (ch & 3) * 16;
     }
+    const int xkstride = xpacked ? (LR_BK / 8) * 512 : LR_BK * 2;   // bytes per k-tile along a row
     const char *wsrc = reinterpret_cast<const char *>(Wimg) + lane * 16;
     auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
         const int k2 = kt < nk ? kt : nk - 1;                  // past-the-end: re-read the last tile (uniform vmcnt)
         char *dst = smem + stage * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + k2 * (LR_BK * 2), dst + (wave + i * NW) * 1024);
+        for (int i = 0; i < 2; ++i) glds16(xsrc[i] + k2 * xkstride, dst + (wave + i * NW) * 1024);
 #pragma unroll
         for (int i = 2; i < PPW; ++i)
             glds16(wsrc + (int64_t)k2 * LR_WBYTES + (wave + i * NW - XP) * 1024, dst + (wave + i * NW) * 1024);
@@ -1614,7 +1694,7 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
 // (exp underflows to exactly 0).  Operands come straight from HBM/L2 (each byte of qkv is read once per query block);
 // FLOPs are ~S/(6H) of the layer's (<1 % at the benchmark's 16-token mean length): HBM/latency-bound.
 // =====================================================================================================
-template <int DH, bool REL>
+template <int DH, bool REL, bool PK = false>   // PK: qkv is in the block-packed layout (packed_off); ctx stays row-major
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 6 : 4))) void attention_kernel(const bf16_t *__restrict__ qkv,
                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ col,
                                                         const float *__restrict__ relb, int relw, int H,
@@ -1636,10 +1716,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
 
     bf16x8 qf[KS];
     {
-        const bf16_t *qp = qkv + tq * H3 + head * DH + 8 * h;
+        // element (token, feature) of qkv; every access below is 8 features (16 bytes) at a feature offset that is a multiple of 8
+        const bf16_t *qp = PK ? qkv + packed_off(tq, head * DH + 8 * h, (int)H3) : qkv + tq * H3 + head * DH + 8 * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qf[s] = *reinterpret_cast<const bf16x8 *>(qp + 16 * s);
+            qf[s] = *reinterpret_cast<const bf16x8 *>(qp + (PK ? 2 * 256 : 16) * s);   // +16 features = two groups of 8
         }
     }
     const int qcol = REL ? col[tq] : 0;
@@ -1660,13 +1741,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
         constexpr int CH = DH / 16;                          // 16-byte chunks per half row of V
         uint4 vr[CH];
         {
-            const bf16_t *kp = qkv + tk * H3 + H + head * DH + 8 * h;
-            const bf16_t *vsrc = qkv + tk * H3 + 2 * H + head * DH + h * (DH / 2);
+            const bf16_t *kp = PK ? qkv + packed_off(tk, H + head * DH + 8 * h, (int)H3) : qkv + tk * H3 + H + head * DH + 8 * h;
+            const bf16_t *vsrc = PK ? qkv + packed_off(tk, 2 * H + head * DH + h * (DH / 2), (int)H3)
+                                    : qkv + tk * H3 + 2 * H + head * DH + h * (DH / 2);
             bf16x8 kf[KS];
 #pragma unroll
-            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * s);
+            for (int s = 0; s < KS; ++s) kf[s] = *reinterpret_cast<const bf16x8 *>(kp + (PK ? 2 * 256 : 16) * s);
 #pragma unroll
-            for (int c = 0; c < CH; ++c) vr[c] = *reinterpret_cast<const uint4 *>(vsrc + 8 * c);
+            for (int c = 0; c < CH; ++c) vr[c] = *reinterpret_cast<const uint4 *>(vsrc + (PK ? 256 : 8) * c);
 #pragma unroll
             for (int s = 0; s < KS; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sc, 0, 0, 0);
         }
@@ -1999,7 +2081,7 @@ static int mpnet_bucket(int rel, int num_buckets) {
 template <int BM, int BN, int BK, int WM, int WN, int EPI, int NST = 2>
 static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, const bf16_t *res, const float *gamma,
                        const float *beta, float eps, bf16_t *out, int M, int N, int K, hipStream_t st,
-                       const bf16_t *Wimg = nullptr) {
+                       const bf16_t *Wimg = nullptr, bool xpacked = false) {
     constexpr int lds = gemm_lds_bytes<BM, BN, BK, WM, WN, NST>();
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = gemm_bf16_kernel<BM, BN, BK, WM, WN, EPI, NST>;
@@ -2010,7 +2092,7 @@ static int launch_gemm(const bf16_t *X, const bf16_t *W, const float *bias, cons
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
     if (Wimg && ntiles != 1) return fail(TSIM_EINVAL, "gemm: a packed W image needs BN == N");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, st, X, W, bias, res, gamma, beta, eps, out, M, N, K,
-                       mtiles, ntiles, Wimg);
+                       mtiles, ntiles, Wimg, xpacked ? 1 : 0);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
 }
@@ -2030,11 +2112,12 @@ static int gemm_xres_nw(const bf16_t *X, const bf16_t *W, const float *bias, bf1
     return TSIM_OK;
 }
 
-template <int EPI>
+template <int EPI, bool PK>
 static int gemm_xres2(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
     constexpr int lds = X2_NSTAGE * X2_BN * X2_BK * 2 + 8192;   // ring | bias (N <= 2048)
     if (N > 2048) return fail(TSIM_EUNSUPPORTED, "gemm_xres2: N=%d > 2048", N);
-    auto kern = gemm_xres2_kernel<EPI>;
+    if (((int64_t)M + 256) * N * 2 >= (1ll << 32)) return fail(TSIM_EUNSUPPORTED, "gemm_xres2: output of %d x %d exceeds 4 GiB", M, N);
+    auto kern = gemm_xres2_kernel<EPI, PK>;
     static DevOnce lds_once;
     TSIM_MAX_LDS(lds_once, kern, lds);
     const int items = ((M + 255) / 256) * (N / X2_BN);
@@ -2048,7 +2131,7 @@ template <int EPI>
 static int gemm_xres(const bf16_t *X, const bf16_t *W, const float *bias, bf16_t *out, int M, int N, hipStream_t st) {
     static int v2 = -1;
     if (v2 < 0) { const char *e = getenv("TSIM_XRES2"); v2 = e ? atoi(e) : 1; }
-    if (v2 && N % X2_BN == 0) return gemm_xres2<EPI>(X, W, bias, out, M, N, st);
+    if (v2 && N % X2_BN == 0) return gemm_xres2<EPI, false>(X, W, bias, out, M, N, st);
     return gemm_xres_nw<EPI, 8>(X, W, bias, out, M, N, st);   // 8 waves = 256 tokens per workgroup (4-wave groups measured slower)
 }
 
@@ -2067,7 +2150,7 @@ static int ffn_fused(const bf16_t *X, const bf16_t *W1img, const bf16_t *W2img, 
 // LayerNorm GEMM of width 384 over rows [0, M) in workgroups of NW * 32 token rows (the last one may be partial)
 template <int NW, int NST, bool STAG = false>
 static int ln_rows_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias, const bf16_t *res, const float *gamma,
-                        const float *beta, float eps, bf16_t *out, int M, int K, hipStream_t st) {
+                        const float *beta, float eps, bf16_t *out, int M, int K, hipStream_t st, bool xpacked) {
     constexpr int lds = NST * (NW * 32 * LR_BK * 2 + LR_WBYTES);   // <8, 3>: 120 KiB, <2, 5>: 140 KiB
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = ln_rows_gemm_kernel<NW, NST, STAG>;
@@ -2075,9 +2158,19 @@ static int ln_rows_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias
     TSIM_MAX_LDS(lds_once, kern, lds);
     if (K % LR_BK != 0 || K < NST * LR_BK) return fail(TSIM_EUNSUPPORTED, "ln_rows_gemm: K=%d", K);
     hipLaunchKernelGGL(kern, dim3((unsigned)((M + NW * 32 - 1) / (NW * 32))), dim3(NW * 64), lds, st, X, Wimg32, bias, res, gamma,
-                       beta, eps, out, M, K);
+                       beta, eps, out, M, K, xpacked ? 1 : 0);
     TSIM_HIP_CHECK(hipGetLastError());
     return TSIM_OK;
+}
+
+// The block-packed qkv / h1 layout (packed_off) needs gemm_xres2 as the producer on both projections
+static bool use_packed_layout(int H, int F) {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("TSIM_PACKED_ACT"), *x2 = getenv("TSIM_XRES2"), *xr = getenv("TSIM_GEMM_XRES"), *bg = getenv("TSIM_GEMM_BIG");
+        on = (e ? atoi(e) : 1) && (x2 ? atoi(x2) : 1) && (xr ? atoi(xr) : 1) && (bg ? atoi(bg) != 2 : 1);
+    }
+    return on && H == 384 && (3 * H) % X2_BN == 0 && F % X2_BN == 0 && F <= 2048;
 }
 
 template <int EPI>
@@ -2096,7 +2189,8 @@ static int gemm_plain(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const 
 
 static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const float *bias, const bf16_t *res,
                        const float *gamma, const float *beta, float eps, bf16_t *out, int M, int N, int K, float *ybuf,
-                       hipStream_t st, const bf16_t *Wimg = nullptr, const bf16_t *Wimg32 = nullptr) {
+                       hipStream_t st, const bf16_t *Wimg = nullptr, const bf16_t *Wimg32 = nullptr, bool xpacked = false) {
+    if (xpacked && N != 384) return fail(TSIM_EINVAL, "gemm_res_ln: the packed operand layout is a hidden-384 form");
     static int use_img = -1;
     if (use_img < 0) { const char *e = getenv("TSIM_LN_WIMG"); use_img = e ? atoi(e) : 1; }
     if (!use_img) Wimg = nullptr;
@@ -2130,8 +2224,8 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 if (use > 0) {
                     static int stag = -1;
                     if (stag < 0) { const char *e = getenv("TSIM_LN_ROWS_STAG"); stag = e ? atoi(e) : 0; }   // measured equal (68.5 vs 66-68 us per launch): off
-                    int rc = stag ? ln_rows_gemm<8, 4, true>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st)
-                                  : ln_rows_gemm<8, 3>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st);
+                    int rc = stag ? ln_rows_gemm<8, 4, true>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st, xpacked)
+                                  : ln_rows_gemm<8, 3>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st, xpacked);
                     const int m1 = use * 256;
                     if (rc || m1 == M) return rc;
                     X += (int64_t)m1 * K; res += (int64_t)m1 * N; out += (int64_t)m1 * N; M -= m1;
@@ -2142,13 +2236,13 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 static int rows_tail = -1;
                 if (rows_tail < 0) { const char *e = getenv("TSIM_LN_ROWS_TAIL"); rows_tail = e ? atoi(e) : 0; }
                 if (rows_tail && after_rows && M <= 128 * 64 && K >= 5 * LR_BK)
-                    return ln_rows_gemm<2, 5>(X, Wimg32, bias, res, gamma, beta, eps, out, M, K, st);
+                    return ln_rows_gemm<2, 5>(X, Wimg32, bias, res, gamma, beta, eps, out, M, K, st, xpacked);
             }
             const int mt = (M + 127) / 128, full = (mt / 256) * 256, rem = mt - full;
             // (four 32-k ring slots instead of two 64-k ones — prefetch distance 3 — measured 2.5 % SLOWER per forward: the deep
             // path issues a k-tile's DMA pieces in one burst ahead of the MFMAs instead of behind each k-step's)
             auto main_launch = [&](int rows) {
-                return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st, Wimg);
+                return launch_gemm<128, 384, 64, 2, 4, EPI_RES_LN>(X, W, bias, res, gamma, beta, eps, out, rows, N, K, st, Wimg, xpacked);
             };
             if (split && rem > 0 && rem <= 96 && (full > 0 || after_rows)) {
                 const int m_main = full * 128;
@@ -2163,9 +2257,9 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 if (tail_bm < 0) { const char *e = getenv("TSIM_LN_TAIL_BM"); tail_bm = e ? atoi(e) : 64; }
                 if (tail_bm == 64)
                     return launch_gemm<64, 384, 64, 2, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
-                                                                      gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg);
+                                                                      gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg, xpacked);
                 return launch_gemm<32, 384, 64, 1, 4, EPI_RES_LN>(X + (int64_t)m_main * K, W, bias, res + (int64_t)m_main * N,
-                                                                  gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg);
+                                                                  gamma, beta, eps, out + (int64_t)m_main * N, M - m_main, N, K, st, Wimg, xpacked);
             }
             return main_launch(M);
         }
@@ -2382,6 +2476,8 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
         TSIM_HIP_CHECK(hipGetLastError());
         const float scale = 1.0f / sqrtf((float)dh);
         const bool rel = c.arch == TSIM_ARCH_MPNET;
+        // qkv and h1 in the block-packed layout (packed_off) when gemm_xres2 produces them: hidden 384, BERT family
+        const bool pk = !mx && !rel && use_packed_layout(H, F);
         const int32_t *col = rel ? (tok_col ? tok_col : tok_pos) : nullptr;
         const int qblocks = (max_len + 31) / 32 > 0 ? (max_len + 31) / 32 : 1;
         const dim3 agrid((unsigned)B, (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
@@ -2391,11 +2487,16 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                         // previous layer's LayerNorm kernel, for layer 0 from the stand-alone quantiser
                 if (l == 0 && (rc = quant_mx(e->x0, T, H, e->aq, e->as, st))) return rc;
                 if ((rc = gemm_pp_mx(PP_EPI_BIAS, e->aq, e->as, L.qqkv, 1, L.sqkv, L.bqkv, e->qkv, nullptr, T, 3 * H, H, st))) return rc;
+            } else if (pk) {
+                if ((rc = gemm_xres2<EPI_BIAS, true>(e->x0, L.wqkv, L.bqkv, e->qkv, T, 3 * H, st))) return rc;
             } else if ((rc = gemm_plain<EPI_BIAS>(e->x0, L.wqkv, L.pqkv, L.bqkv, e->qkv, T, 3 * H, H, st))) return rc;
 #define ATT(D)                                                                                                 \
     do {                                                                                                       \
         if (rel)                                                                                               \
             hipLaunchKernelGGL((attention_kernel<D, true>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col,  \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+        else if (pk)                                                                                           \
+            hipLaunchKernelGGL((attention_kernel<D, false, true>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col, \
                                e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
         else                                                                                                   \
             hipLaunchKernelGGL((attention_kernel<D, false>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col, \
@@ -2423,8 +2524,10 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
                 if ((rc = ffn_fused(e->x1, L.p1, L.p2, L.b1, L.b2, L.g2, L.be2, c.ln_eps, e->x0, T, F, st))) return rc;
                 continue;
             }
-            if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, nullptr, L.b1, e->h1, T, F, H, st))) return rc;
-            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st, L.l2, L.l232))) return rc;
+            if (pk) {
+                if ((rc = gemm_xres2<EPI_GELU, true>(e->x1, L.w1, L.b1, e->h1, T, F, st))) return rc;
+            } else if ((rc = gemm_plain<EPI_GELU>(e->x1, L.w1, nullptr, L.b1, e->h1, T, F, H, st))) return rc;
+            if ((rc = gemm_res_ln(e->h1, L.w2, nullptr, L.b2, e->x1, L.g2, L.be2, c.ln_eps, e->x0, T, H, F, e->ybuf, st, L.l2, L.l232, pk))) return rc;
         }
         if (last_hidden_bf16)
             TSIM_HIP_CHECK(hipMemcpyAsync(last_hidden_bf16, e->x0, (size_t)T * H * 2, hipMemcpyDeviceToDevice, st));

@@ -31,8 +31,11 @@ __device__ __forceinline__ void glds16(const void *g, void *l) {
 
 // NW waves; READS: fragment reads from LDS (else the MFMA operand stays in a register); BAR: barrier per SPB steps; DMA: pieces per
 // wave and step (0: none); M16: 16x16x32 form (2 MFMAs per read); LATE: waves >= NW/2 issue their DMA after their MFMAs
-template <int NW, bool READS, int SPB, int DMA, bool M16, bool LATE>
-__global__ __launch_bounds__(NW * 64) void loop_kernel(const char *__restrict__ src, int steps, unsigned long long *__restrict__ cyc, float *__restrict__ sink) {
+// ST: 0 none; 1: two 16-byte stores per wave and step in gemm_xres2's pattern (32 token rows x 32 B, rows 2 304 B apart);
+// 2: the same bytes as two contiguous 1-KiB stores; 3: pattern 1 issued inside the MFMA stream (behind MFMAs 14 and 20)
+template <int NW, bool READS, int SPB, int DMA, bool M16, bool LATE, int ST = 0>
+__global__ __launch_bounds__(NW * 64) void loop_kernel(const char *__restrict__ src, int steps, unsigned long long *__restrict__ cyc, float *__restrict__ sink,
+                                                       char *__restrict__ dst = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 24576, NSLOT = 4, NM = 24;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,6 +64,13 @@ __global__ __launch_bounds__(NW * 64) void loop_kernel(const char *__restrict__ 
 #pragma unroll
         for (int i = 0; i < DMA; ++i)
             glds16(my + ((wave * (DMA > 0 ? DMA : 1) + i) % 24) * 1024, smem + ((st + 2) % NSLOT) * TILE + ((wave * (DMA > 0 ? DMA : 1) + i) % 24) * 1024);
+    };
+    char *drow = dst + (size_t)blockIdx.x * (256 * 2304) + (ST == 2 ? (size_t)wave * 32 * 2304 + lane * 16 : (size_t)(wave * 32 + r) * 2304 + 16 * h);
+    auto do_store = [&](int st, int which) __attribute__((always_inline)) {
+        const u32x4 v = {(uint32_t)st, (uint32_t)lane, 0x3c003c00u, (uint32_t)which};
+        char *a = drow + ((st * 2 + which) % 36) * (ST == 2 ? 1024 : 64);
+        if (ST == 2) a = drow + ((st * 2 + which) % 64) * 1024;
+        *reinterpret_cast<u32x4 *>(a) = v;
     };
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -95,7 +105,15 @@ __global__ __launch_bounds__(NW * 64) void loop_kernel(const char *__restrict__ 
             } else {
                 acc[n % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]), b, acc[n % 3], 0, 0, 0);
             }
+            if constexpr (ST == 3 && n == 14) do_store(st, 0);
+            if constexpr (ST == 3 && n == 20) do_store(st, 1);
         });
+        if constexpr (ST == 1 || ST == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(acc[i]));
+            do_store(st, 0);
+            do_store(st, 1);
+        }
         if constexpr (DMA > 0) {
             if (late) {
 #pragma unroll
@@ -115,16 +133,16 @@ __global__ __launch_bounds__(NW * 64) void loop_kernel(const char *__restrict__ 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int NW, bool READS, int SPB, int DMA, bool M16, bool LATE>
-static void run(const char *name, const char *src, unsigned long long *cyc, float *sink, int steps) {
-    auto k = loop_kernel<NW, READS, SPB, DMA, M16, LATE>;
+template <int NW, bool READS, int SPB, int DMA, bool M16, bool LATE, int ST = 0>
+static void run(const char *name, const char *src, unsigned long long *cyc, float *sink, int steps, char *dst = nullptr) {
+    auto k = loop_kernel<NW, READS, SPB, DMA, M16, LATE, ST>;
     const int lds = 4 * 24576;
     hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(256), dim3(NW * 64), lds, 0, src, steps, cyc, sink);
+        hipLaunchKernelGGL(k, dim3(256), dim3(NW * 64), lds, 0, src, steps, cyc, sink, dst);
         hipEventRecord(e1);
         hipDeviceSynchronize();
     }
@@ -151,6 +169,11 @@ int main() {
     run<8, true, 1, 8, false, false>("8 waves, reads + barrier + 8 DMA pieces/wave/step", src, cyc, sink, S);
     run<8, true, 1, 3, true, false>("8 waves, 16x16x32 form, reads + barrier + 3 DMA", src, cyc, sink, S);
     run<8, true, 1, 0, true, false>("8 waves, 16x16x32 form, reads + barrier", src, cyc, sink, S);
+    char *dst;
+    hipMalloc(&dst, (size_t)256 * 256 * 2304 + (1 << 20));
+    run<8, true, 1, 3, false, false, 1>("8 waves, reads + barrier + 3 DMA + 2 stores (32 rows x 32 B)", src, cyc, sink, S, dst);
+    run<8, true, 1, 3, false, false, 2>("8 waves, reads + barrier + 3 DMA + 2 stores (contiguous 1 KiB)", src, cyc, sink, S, dst);
+    run<8, true, 1, 3, false, false, 3>("8 waves, reads + barrier + 3 DMA + 2 stores (32 x 32 B) in stream", src, cyc, sink, S, dst);
     run<4, false, 100000, 0, false, false>("4 waves, MFMA only", src, cyc, sink, S);
     run<4, true, 100000, 0, false, false>("4 waves, + ds_read_b128 per MFMA", src, cyc, sink, S);
     run<4, true, 1, 6, false, false>("4 waves, reads + barrier + 6 DMA pieces/wave/step", src, cyc, sink, S);

@@ -81,38 +81,139 @@ struct ExactQuery {
     double norm;         // COS: max(|q|, eps)
 };
 
-template <typename T, bool COS>
-__device__ __forceinline__ void exact_load_query(ExactQuery<T> &q, const T *row, int d, int lane) {
+// This lane's elements j = lane + 64 i, i < NI, of a row as float64 (0 beyond d).  BRANCH-FREE: the address of an element past
+// the end is clamped to the row's last one and the value replaced after the load.  (`j < d ? load : 0` compiles to a branch
+// around every load with s_waitcnt vmcnt(0) behind it: the six loads of a 384-wide row became six dependent round trips, the
+// 16 candidates of a query 96 — 45 of the finalize kernel's 88 us at Q = 256.)  1 <= d <= 64 NI.
+template <typename T, int NI>
+__device__ __forceinline__ void row_elems_f64(double (&c)[NI], const T *row, int d, int lane) {
+    float x[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = lane + 64 * i;
+        x[i] = load_as_f32<T>(row + (j < d ? j : d - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) c[i] = lane + 64 * i < d ? (double)x[i] : 0.0;
+}
+
+template <typename T, bool COS, int NI>
+__device__ __forceinline__ void exact_load_query_ni(ExactQuery<T> &q, const T *row, int d, int lane) {
+    double c[NI];
+    row_elems_f64<T, NI>(c, row, d, lane);
     double ss = 0.0;
 #pragma unroll
     for (int i = 0; i < XS_MAXI; ++i) {
-        const int j = lane + 64 * i;
-        q.v[i] = j < d ? (double)load_as_f32<T>(row + j) : 0.0;
-        ss = fma(q.v[i], q.v[i], ss);
+        q.v[i] = i < NI ? c[i < NI ? i : 0] : 0.0;
+        ss = fma(q.v[i], q.v[i], ss);   // (+0 beyond d: the sum is that of the elements below d, in their order)
     }
     q.norm = 1.0;
     if constexpr (COS) q.norm = fmax(sqrt(wave_sum_f64(ss)), XS_EPS);
+}
+template <typename T, bool COS>
+__device__ __forceinline__ void exact_load_query(ExactQuery<T> &q, const T *row, int d, int lane) {
+    if (d <= 64 * (XS_MAXI / 2)) exact_load_query_ni<T, COS, XS_MAXI / 2>(q, row, d, lane);   // wave-uniform
+    else exact_load_query_ni<T, COS, XS_MAXI>(q, row, d, lane);
+}
+
+// per-lane partial sums of the query against one row: dot (and |row|^2 for COS)
+template <typename T, bool COS, int NI>
+__device__ __forceinline__ void exact_partials(const ExactQuery<T> &q, const T *row, int d, int lane, double &dot, double &cc) {
+    double c[NI];
+    row_elems_f64<T, NI>(c, row, d, lane);
+    dot = 0.0;
+    cc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        dot = fma(q.v[i], c[i], dot);
+        if constexpr (COS) cc = fma(c[i], c[i], cc);
+    }
 }
 
 // exact score of the query against one row (all 64 lanes take part and get the same value)
 template <typename T, bool COS>
 __device__ __forceinline__ float exact_score(const ExactQuery<T> &q, const T *row, int d, int lane) {
-    double dot = 0.0, cc = 0.0;
-#pragma unroll
-    for (int i = 0; i < XS_MAXI; ++i) {
-        const int j = lane + 64 * i;
-        if (64 * i < d) {   // wave-uniform
-            const double c = j < d ? (double)load_as_f32<T>(row + j) : 0.0;
-            dot = fma(q.v[i], c, dot);
-            if constexpr (COS) cc = fma(c, c, cc);
-        }
-    }
+    double dot, cc;
+    if (d <= 64 * (XS_MAXI / 2)) exact_partials<T, COS, XS_MAXI / 2>(q, row, d, lane, dot, cc);   // wave-uniform
+    else exact_partials<T, COS, XS_MAXI>(q, row, d, lane, dot, cc);
     dot = wave_sum_f64(dot);
     if constexpr (COS) {
         const double nc = fmax(sqrt(wave_sum_f64(cc)), XS_EPS);
         return (float)(dot / (q.norm * nc));
     }
     return (float)dot;
+}
+
+// NB rows against the query at once: lane t0 + u (u < NB) returns the exact score of the row held (as my_i) by lane
+// t0 + u < nvalid; other lanes return garbage.  Same bits as exact_score: per lane the same fma chains, and the wave sums are
+// the SAME xor-butterfly trees (32, 16, .., 1) — evaluated as a reduce-scatter: with NV values to sum, a lane sends the half of
+// them its partner keeps and adds what it receives to the half it keeps itself (own + partner commutes, so both lanes of a
+// pair would have computed the same bits), NV/2 + NV/4 + .. exchanges instead of 6 NV.  All NB rows' loads are in flight
+// together: one memory round trip per batch — at small Q this kernel is a chain of round trips and butterflies and nothing else
+// (one wave per query, 64 workgroups at Q = 256: 45 of its 88 us were four dependent gathers of four rows each).
+template <int N, int O, int NV>   // N values still held per lane, next exchange with lane ^ O (compile-time indices throughout)
+__device__ __forceinline__ void butterfly_reduce_scatter(double (&acc)[NV], int lane) {
+    if constexpr (O > 0) {
+        if constexpr (N > 1) {
+            const bool up = (lane & O) != 0;   // this lane keeps the upper half
+#pragma unroll
+            for (int v = 0; v < N / 2; ++v) {
+                const double send = up ? acc[v] : acc[v + N / 2];
+                const double keep = up ? acc[v + N / 2] : acc[v];
+                acc[v] = keep + __shfl_xor(send, O, 64);
+            }
+            butterfly_reduce_scatter<N / 2, O / 2>(acc, lane);
+        } else {
+            acc[0] += __shfl_xor(acc[0], O, 64);
+            butterfly_reduce_scatter<1, O / 2>(acc, lane);
+        }
+    }
+}
+
+template <typename T, bool COS, int NB>
+__device__ __forceinline__ float exact_score_batch(const ExactQuery<T> &q, const T *xc, int64_t ldc, int my_i, int t0, int nvalid,
+                                                   int d, int lane) {
+    constexpr int NV = (COS ? 2 : 1) * NB;
+    static_assert(NV >= 2 && NV <= 32 && (NV & (NV - 1)) == 0, "batch size");
+    constexpr int LOG = NV == 32 ? 5 : NV == 16 ? 4 : NV == 8 ? 3 : NV == 4 ? 2 : 1;
+    double acc[NV];
+    const T *rows[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int t = t0 + u < nvalid ? t0 + u : t0;   // past the end: repeat a valid one, result unused
+        rows[u] = xc + (int64_t)__shfl(my_i, t, 64) * ldc;
+    }
+    if (d <= 64 * (XS_MAXI / 2)) {   // wave-uniform
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            double dot, cc;
+            exact_partials<T, COS, XS_MAXI / 2>(q, rows[u], d, lane, dot, cc);
+            if constexpr (COS) { acc[2 * u] = dot; acc[2 * u + 1] = cc; }
+            else acc[u] = dot;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            double dot, cc;
+            exact_partials<T, COS, XS_MAXI>(q, rows[u], d, lane, dot, cc);
+            if constexpr (COS) { acc[2 * u] = dot; acc[2 * u + 1] = cc; }
+            else acc[u] = dot;
+        }
+    }
+    butterfly_reduce_scatter<NV, 32>(acc, lane);
+    // value v ended up in the lanes with (lane >> (6 - LOG)) == v
+    constexpr int SH = 6 - LOG;
+    float score;
+    if constexpr (COS) {
+        const double other = __shfl_xor(acc[0], 1 << SH, 64);          // even v (dot) lanes receive cc
+        const double nc = fmax(sqrt(other), XS_EPS);
+        score = (float)(acc[0] / (q.norm * nc));
+    } else {
+        score = (float)acc[0];
+    }
+    const int u = lane - t0;
+    const int src = ((COS ? 2 * u : u) << SH) & 63;
+    return __shfl(score, src, 64);
 }
 
 __device__ __forceinline__ bool key_before(float s1, int i1, float s2, int i2) {
@@ -153,14 +254,18 @@ struct GuardArgs {
 __device__ __forceinline__ float query_rho(const ExactQuery<float> &q, const unit_t *urow, int d, int lane) {
     double r2 = 0.0;
     const double inv = 1.0 / q.norm;
+    auto body = [&](auto nic) __attribute__((always_inline)) {
+        constexpr int NI = decltype(nic)::value;
+        double u[NI];
+        row_elems_f64<unit_t, NI>(u, urow, d, lane);
 #pragma unroll
-    for (int i = 0; i < XS_MAXI; ++i) {
-        const int j = lane + 64 * i;
-        if (j < d) {
-            const double e = (double)(float)urow[j] - q.v[i] * inv;
+        for (int i = 0; i < NI; ++i) {
+            const double e = u[i] - q.v[i] * inv;   // (0 - 0 beyond d)
             r2 = fma(e, e, r2);
         }
-    }
+    };
+    if (d <= 64 * (XS_MAXI / 2)) body(std::integral_constant<int, XS_MAXI / 2>{});   // wave-uniform
+    else body(std::integral_constant<int, XS_MAXI>{});
     return rho_round_up(sqrt(wave_sum_f64(r2)));
 }
 __device__ __forceinline__ float guard_rho_c(const GuardArgs &g) { return g.rho_c_max ? *g.rho_c_max : g.rho_c_default; }
@@ -175,7 +280,7 @@ __device__ __forceinline__ float guard_tau(float target, float eps) {
 
 // The KL best entries of a query's partial lists by (MFMA score desc, index asc): lane t < KL returns the t-th
 // (my_i = -1 when there are fewer).  ps / pi: the query's lists, nlists of KL entries each, sorted, padded with (-inf, -1).
-template <int KL>
+template <int KL, int LB = 4>
 __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, const int *__restrict__ pi, int P2, int lane,
                                                float &my_s_out, int &my_i_out) {
     // 1a. one pass: every lane keeps the KL best of its E/64 entries in a sorted register list
@@ -205,8 +310,7 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
     // one memory round trip per 256 lists instead of two per list (the walk was a chain of dependent loads: 16 round trips
     // at Q = 256, where P2 = 512) — and only a list that is full that far is walked on.  (Eight lists at a time cost 32 more
     // registers: 160 instead of <= 128, one wave per SIMD less, and the kernel — pure latency — ran 152 us instead of 80 at
-    // Q = 4096.)
-    constexpr int LB = 4;
+    // Q = 4096; LB = 8 is the small-batch form, where occupancy is idle anyway.)
     for (int l0 = lane; l0 < P2; l0 += 64 * LB) {
         int4 iv[LB];
         float4 sv[LB];
@@ -308,8 +412,11 @@ __global__ __launch_bounds__(256) void thr_update_kernel(const float *__restrict
 //      can reach the list and the result stands; otherwise the query is FLAGGED: the widening pass (K1 in COLLECT mode)
 //      gathers every row whose MFMA score exceeds (k-th exact score - eps) and widen_finalize re-scores all of them.
 // =====================================================================================================
-template <int KL, typename T, bool COS>
-__global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__restrict__ part_s,
+// NB: rows per exact re-score batch, LB: lists per walk round trip.  <4, 4>: 120 registers, four waves per SIMD (large Q: the
+// kernel is latency-bound and lives on occupancy); <16 or 8, 8>: everything in flight at once for Q <= 1024, where at most one
+// workgroup per CU exists anyway.
+template <int KL, typename T, bool COS, int NB, int LB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB > 4 ? 1 : KL == 16 ? 4 : 2))) void cos_topk_finalize_kernel(const float *__restrict__ part_s,
                                                                 const int *__restrict__ part_i, int P2,
                                                                 int64_t Q, int64_t N, const T *__restrict__ xq, int64_t ldq,
                                                                 const T *__restrict__ xc, int64_t ldc, int d, int k,
@@ -331,7 +438,7 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
     my_i = lane < KL ? pi[lane] : -1;
     if (my_i < 0 && lane < KL) { my_i = (int)((q * 977 + lane * 131) % N); my_s = 0.f; }
 #else
-    select_kl_best<KL>(ps, pi, P2, lane, my_s, my_i);
+    select_kl_best<KL, LB>(ps, pi, P2, lane, my_s, my_i);
 #endif
     const int nvalid = __popcll(__ballot(my_i >= 0));   // candidates sit in lanes 0 .. nvalid-1
 
@@ -340,19 +447,13 @@ __global__ __launch_bounds__(256) void cos_topk_finalize_kernel(const float *__r
     exact_load_query<T, COS>(eqr, xq + q * ldq, d, lane);
     float cs = -INFINITY;
 #pragma unroll 1
-    for (int t0 = 0; t0 < nvalid; t0 += 4) {   // four candidates per step: their row reads overlap
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u < nvalid ? t0 + u : t0;   // past the end: repeat a valid one, result unused
-            const int ci = __shfl(my_i, t, 64);
+    for (int t0 = 0; t0 < nvalid; t0 += NB) {   // NB candidates per step: their row reads overlap, their wave sums share shuffles
 #if defined(TSIM_FIN_DIAG) && (TSIM_FIN_DIAG & 2)   // TIMING-ONLY (wrong results): no exact re-score
-            const float sc = __shfl(my_s, t, 64);
-            (void)ci;
+        const float sc = my_s;
 #else
-            const float sc = exact_score<T, COS>(eqr, xc + (int64_t)ci * ldc, d, lane);
+        const float sc = exact_score_batch<T, COS, NB>(eqr, xc, ldc, my_i, t0, nvalid, d, lane);
 #endif
-            if (lane == t0 + u) cs = sc;
-        }
+        if (lane >= t0 && lane < t0 + NB && lane < nvalid) cs = sc;
     }
     // 3. final order among the candidates: rank by counting
     int rank = 0;
@@ -1007,8 +1108,19 @@ template <int KL, typename T, bool COS>
 static void launch_finalize(const TopkPlan &p, const float *part_s, const int *part_i, int64_t Q, int64_t N, const T *xq,
                             int64_t ldq, const T *xc, int64_t ldc, int d, int k, const unit_t *uq, const int *gthr, float *out_s,
                             int64_t *out_i, int64_t idx_offset, const GuardArgs &g, hipStream_t st) {
-    hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS>), dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, part_s, part_i,
-                       p.P2, Q, N, xq, ldq, xc, ldc, d, k, uq, gthr, out_s, out_i, idx_offset, g);
+    const dim3 grid((unsigned)((Q + 3) / 4));
+    constexpr int LBW = KL == 16 ? 8 : 4;   // (eight lists of 32 at a time spill)
+    static int wide_on = -1;
+    if (wide_on < 0) { const char *e = getenv("TSIM_FIN_WIDE"); wide_on = e ? atoi(e) : 1; }
+    if (wide_on && Q <= 1024 && d <= 384)
+        hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS, 16, LBW>), grid, dim3(256), 0, st, part_s, part_i, p.P2, Q, N, xq, ldq,
+                           xc, ldc, d, k, uq, gthr, out_s, out_i, idx_offset, g);
+    else if (wide_on && Q <= 1024)
+        hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS, 8, LBW>), grid, dim3(256), 0, st, part_s, part_i, p.P2, Q, N, xq, ldq,
+                           xc, ldc, d, k, uq, gthr, out_s, out_i, idx_offset, g);
+    else
+        hipLaunchKernelGGL((cos_topk_finalize_kernel<KL, T, COS, 4, 4>), grid, dim3(256), 0, st, part_s, part_i, p.P2, Q, N, xq, ldq,
+                           xc, ldc, d, k, uq, gthr, out_s, out_i, idx_offset, g);
 }
 }  // namespace tsim
 

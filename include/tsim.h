@@ -203,6 +203,26 @@ int tsim_encoder_forward(tsim_encoder *enc, const int32_t *tok_ids, const int32_
 #define TSIM_ENC_ERR_MAX_LEN 4
 int tsim_encoder_error_flags(tsim_encoder *enc, int32_t *flags_host, void *stream);
 
+/* ---- tokenizer (host code, no GPU): BERT WordPiece for pure-ASCII sentences -------------------------------------------------
+ * Replaces, for the sentences it handles, the host tokenizer call of the reference's encode_text
+ * (/root/reference/src/models/sentence_encoder.py:144-153: tokenizer(text=batch, padding=True, truncation=True,
+ * max_length=...)) with the same ids: BertNormalizer (clean_text, lowercase) -> BertPreTokenizer -> WordPiece -> prefix /
+ * suffix special ids -> truncation on the right to max_len, as the `tokenizers` library the reference depends on does it.
+ * The vocabulary is one blob of UTF-8 keys + vocab_size + 1 byte offsets; the id of a key is its position.  `added_*`: the
+ * contents of the library's added / special tokens: a sentence containing one of them, or any non-ASCII byte, is NOT
+ * handled.  Thread-safe after creation. */
+int tsim_wordpiece_create(const char *vocab_text, const int64_t *vocab_offsets, int32_t vocab_size,
+                          const char *continuing_prefix, int32_t unk_id, const int32_t *prefix_ids, int32_t n_prefix,
+                          const int32_t *suffix_ids, int32_t n_suffix, int32_t lowercase, int32_t max_input_chars_per_word,
+                          const char *added_text, const int64_t *added_offsets, int32_t n_added, void **handle);
+void tsim_wordpiece_destroy(void *handle);
+/* n sentences (one blob + n + 1 byte offsets) on n_threads host threads (<= 0: all cores).  out_ids receives the ids of the
+ * handled sentences back to back (sentence order); out_capacity (in ids) must be at least sum_i min(max_len, bytes_i +
+ * specials), e.g. total bytes + n * specials, else TSIM_ENOMEM.  out_lens[i] = ids of sentence i (0 when not handled),
+ * handled[i] = 1 / 0: the caller tokenises the others with the library itself. */
+int tsim_wordpiece_encode(void *handle, const char *text, const int64_t *text_offsets, int64_t n, int32_t max_len,
+                          int32_t n_threads, int32_t *out_ids, int64_t out_capacity, int32_t *out_lens, uint8_t *handled);
+
 #ifdef __cplusplus
 }
 #endif

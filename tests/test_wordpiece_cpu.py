@@ -1,0 +1,152 @@
+"""Native ASCII WordPiece tokenizer (csrc/wordpiece.cpp) against its oracle: the `tokenizers` library behind the
+HuggingFace BertTokenizer the reference is configured with (sentence_encoder.py:144-153).  Host code only: runs without a GPU.
+No published vocabulary ships with the reference or this image, so the vocabularies are generated here (whole words,
+'##' continuations, single characters, punctuation): the ALGORITHM is what is compared, id for id."""
+import random
+import string
+
+import numpy as np
+import pytest
+
+from text_similarity_amd import presets
+from text_similarity_amd.models.sentence_encoder import _tokenize_library, _tokenize_packed
+from text_similarity_amd.wordpiece import NativeWordPiece
+
+transformers = pytest.importorskip("transformers")
+
+
+def _piece_vocab(seed=7, n_words=3000, n_cont=1500):
+    rng = random.Random(seed)
+    vocab = {"[PAD]": 0}
+    for i in range(1, 100):
+        vocab[f"[unused{i}]"] = i
+    vocab["[UNK]"], vocab["[CLS]"], vocab["[SEP]"], vocab["[MASK]"] = 100, 101, 102, 103
+
+    def add(k):
+        if k not in vocab:
+            vocab[k] = len(vocab)
+
+    for c in string.ascii_lowercase + string.digits:      # single characters, but not every continuation: some words -> [UNK]
+        add(c)
+    for c in "aeiourstln0123":
+        add("##" + c)
+    for c in "!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~":
+        if c not in "^~`":                                   # some punctuation is out of vocabulary
+            add(c)
+    syll = ["ab", "an", "ing", "er", "th", "on", "re", "st", "en", "qu", "ly", "tion", "un", "pre", "x", "zz", "the", "and"]
+    for _ in range(n_words):
+        add("".join(rng.choice(syll) for _ in range(rng.randint(1, 4))))
+    for _ in range(n_cont):
+        add("##" + "".join(rng.choice(syll) for _ in range(rng.randint(1, 3))))
+    add("##")                                                # degenerate keys the matcher must not trip over
+    add("a" * 101)
+    return vocab, syll
+
+
+def _tok(vocab, lower=True):
+    return transformers.BertTokenizer(vocab=vocab, do_lower_case=lower)
+
+
+def _sentences(syll, n, seed):
+    rng = random.Random(seed)
+    punct = "!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~"
+    out = []
+    for _ in range(n):
+        words = []
+        for _ in range(rng.randint(0, 40)):
+            r = rng.random()
+            if r < 0.6:
+                w = "".join(rng.choice(syll) for _ in range(rng.randint(1, 5)))
+            elif r < 0.7:
+                w = "".join(rng.choice(string.ascii_letters + string.digits) for _ in range(rng.randint(1, 12)))
+            elif r < 0.8:
+                w = rng.choice(punct) * rng.randint(1, 3)
+            elif r < 0.9:
+                w = rng.choice(syll) + rng.choice(punct) + rng.choice(syll)
+            else:
+                w = rng.choice(syll).upper() + rng.choice(["", "'s", "-", "..."])
+            words.append(w)
+        sep = rng.choice([" ", "  ", "\t", "\n", " \r\n "])
+        out.append(sep.join(words))
+    return out
+
+
+HAND = [
+    "", " ", "\t\n", "a", "A", "the", "THE and The", "hello, world!", "x" * 100, "x" * 101, "a" * 101, "ab" * 60,
+    "tab\tseparated\nlines\r\nhere", "ctrl\x01chars\x1fin\x7fside", "nul\x00byte", "vertical\x0btab form\x0cfeed",
+    "don't stop-me_now (ever) [really] {no}", "a.b.c...d", "##ing ## #", "^caret~tilde`tick", "price: $5.00 + 10% = ?",
+    "[CLS] literal special", "ends with [SEP]", "mask [MASK] here", "[unused5] is plain text", "[UNK]", "[ CLS ]",
+    "café au lait", "你好 world", "emoji \U0001f600 ok", "naïve", "zero​width",
+    " leading and trailing ", "MiXeD CaSe WoRdS", "9 99 999 9999a a9999", "ing", "thethethe", "unprequ" * 20,
+]
+
+
+@pytest.mark.parametrize("lower", [True, False])
+@pytest.mark.parametrize("max_len", [256, 16, 3, 2])
+def test_native_wordpiece_matches_the_library(lower, max_len):
+    vocab, syll = _piece_vocab()
+    tok = _tok(vocab, lower)
+    wp = NativeWordPiece.from_tokenizer(tok)
+    assert wp is not None, "BertTokenizer's backend must be recognised"
+    docs = HAND + _sentences(syll, 1500, seed=11 + max_len)
+    ref_flat, ref_lens = _tokenize_library(tok, docs, max_len, 64)
+    flat, lens = wp.tokenize_packed(docs, max_len, lambda rest: _tokenize_library(tok, rest, max_len, 64))
+    assert np.array_equal(lens, ref_lens)
+    assert np.array_equal(flat, ref_flat)
+    # ... and the native code did the work for the ASCII sentences without added-token text
+    asc = [d for d in docs if d.isascii()]
+    _, _, handled = wp.encode_ascii(asc, max_len)
+    specials = ("[CLS]", "[SEP]", "[MASK]", "[UNK]", "[PAD]")
+    assert [bool(h) for h in handled] == [not any(s in d for s in specials) for d in asc]
+    assert handled.sum() > 1400
+
+
+def test_every_sentence_alone_equals_the_batch():
+    """No state leaks between sentences or threads: a batch equals its sentences tokenised one by one, on 1 and on 5 threads."""
+    vocab, syll = _piece_vocab(seed=3)
+    tok = _tok(vocab)
+    wp = NativeWordPiece.from_tokenizer(tok)
+    docs = [d for d in _sentences(syll, 700, seed=5) if d.isascii()]
+    wp.threads = 5
+    flat, lens, handled = wp.encode_ascii(docs, 64)
+    assert handled.all()
+    wp.threads = 1
+    flat1, lens1, _ = wp.encode_ascii(docs, 64)
+    assert np.array_equal(flat, flat1) and np.array_equal(lens, lens1)
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    for i in range(0, len(docs), 37):
+        one, l1, _ = wp.encode_ascii([docs[i]], 64)
+        assert np.array_equal(one, flat[cu[i]:cu[i + 1]]) and l1[0] == lens[i]
+
+
+def test_tokenize_packed_uses_the_native_path_and_the_bench_vocabulary(monkeypatch):
+    """The benchmark's tokenizer (presets.synthetic_vocab: whole-word entries) through the product entry point, native on and
+    off: same ids; an unsupported tokenizer keeps the library path."""
+    tok = _tok(presets.synthetic_vocab(2000))
+    docs = presets.synthetic_sentences(600, seed="wp-test", vocab_size=2000) + ["unknownword w00105", "w00110é"]
+    flat, lens = _tokenize_packed(tok, docs, 32, 64)
+    assert getattr(tok, "_tsim_native_wordpiece", None), "native tokenizer was not built for a BERT tokenizer"
+    monkeypatch.setenv("TSIM_NATIVE_TOKENIZER", "0")
+    tok2 = _tok(presets.synthetic_vocab(2000))
+    flat2, lens2 = _tokenize_packed(tok2, docs, 32, 64)
+    assert getattr(tok2, "_tsim_native_wordpiece", None) is False
+    assert np.array_equal(flat, flat2) and np.array_equal(lens, lens2)
+
+    class NotBert:
+        is_fast = False
+    assert NativeWordPiece.from_tokenizer(NotBert()) is None
+
+
+def test_capacity_is_checked():
+    import ctypes as C
+    from text_similarity_amd import _lib
+    vocab, _ = _piece_vocab()
+    wp = NativeWordPiece.from_tokenizer(_tok(vocab))
+    text = b"the and the"
+    off = np.array([0, len(text)], dtype=np.int64)
+    ids = np.empty(4, dtype=np.int32)
+    lens = np.empty(1, dtype=np.int32)
+    handled = np.empty(1, dtype=np.uint8)
+    rc = _lib.lib().tsim_wordpiece_encode(wp._h, text, off.ctypes.data, 1, 64, 1, ids.ctypes.data, 4, lens.ctypes.data,
+                                          handled.ctypes.data)
+    assert rc == 3      # TSIM_ENOMEM: out_capacity below bytes + specials

@@ -58,6 +58,11 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p]),
     "tsim_topk_merge_strided": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsim_wordpiece_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "tsim_wordpiece_destroy": (None, [C.c_void_p]),
+    "tsim_wordpiece_encode": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p]),
     "tsim_cos_sim": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "tsim_mean_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]),

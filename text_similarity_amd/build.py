@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 TAG = os.environ.get("TSIM_BUILD_TAG", "")
 OBJ = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
 LIB = os.path.join(HERE, "libtsim" + ("_" + TAG if TAG else "") + ".so")
-SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_d384.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip"]
+SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_d384.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip",
+           "wordpiece.cpp"]   # (host-only C++: the ASCII WordPiece tokenizer)
 HOT_KERNELS = ("cos_topk_partial", "cos_topk_finalize", "gemm_bf16", "gemm_xres", "ln_rows_gemm", "gemm_pp", "attention_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
@@ -47,7 +48,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), only=None) 
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
         if only is not None and s not in only:
             if not os.path.exists(obj):
                 raise RuntimeError(f"--only: {obj} does not exist yet")
@@ -92,9 +93,9 @@ def build(force: bool = False, verbose: bool = True, extra_flags=(), only=None) 
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in srcs]
     if force or jobs or not _newer(LIB, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

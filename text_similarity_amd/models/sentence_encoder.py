@@ -8,6 +8,7 @@ What is reproduced is the *intended* behaviour: ``encode_text`` 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Union
 
 import numpy as np
@@ -20,7 +21,32 @@ from ..native_encoder import NativeEncoder
 from .modeling import BaseEncoderModel, _native_from_dir
 
 
+def _native_wordpiece(tokenizer):
+    """The tokenizer's NativeWordPiece (built once, kept on the tokenizer object), or None when its pipeline is not BERT's,
+    the library is not built, or TSIM_NATIVE_TOKENIZER=0."""
+    wp = getattr(tokenizer, "_tsim_native_wordpiece", None)
+    if wp is None:
+        wp = False
+        if os.environ.get("TSIM_NATIVE_TOKENIZER", "1") != "0":
+            from ..wordpiece import NativeWordPiece
+            wp = NativeWordPiece.from_tokenizer(tokenizer) or False
+        try:
+            tokenizer._tsim_native_wordpiece = wp
+        except Exception:
+            pass
+    return wp or None
+
+
 def _tokenize_packed(tokenizer, docs: List[str], max_len: int, batch_size: int):
+    """Tokenise without padding -> (flat ids int32, lengths): the native WordPiece path for the sentences it handles (pure
+    ASCII; csrc/wordpiece.cpp — same ids, tests/test_wordpiece_cpu.py), the library for the rest."""
+    wp = _native_wordpiece(tokenizer)
+    if wp is not None:
+        return wp.tokenize_packed(docs, int(max_len), lambda rest: _tokenize_library(tokenizer, rest, max_len, batch_size))
+    return _tokenize_library(tokenizer, docs, max_len, batch_size)
+
+
+def _tokenize_library(tokenizer, docs: List[str], max_len: int, batch_size: int):
     """Tokenise without padding -> (flat ids int32, lengths).  Same tokenizer kwargs as
     sentence_encoder.py:144-153 except padding: the packed layout has no pad tokens, which is equivalent
     because padded positions are masked out of attention and pooling.

@@ -20,7 +20,7 @@ OBJ = os.path.join(CSRC, "_obj" + ("_" + TAG if TAG else ""))
 LIB = os.path.join(HERE, "libtsim" + ("_" + TAG if TAG else "") + ".so")
 SOURCES = ["common.hip", "search.hip", "k1_kl16.hip", "k1_d384.hip", "k1_kl32.hip", "k1_collect.hip", "gemm_pp.hip", "encoder.hip",
            "wordpiece.cpp"]   # (host-only C++: the ASCII WordPiece tokenizer)
-HOT_KERNELS = ("cos_topk_partial", "cos_topk_finalize", "gemm_bf16", "gemm_xres", "ln_rows_gemm", "gemm_pp", "attention_kernel")
+HOT_KERNELS = ("cos_topk_partial", "cos_topk_finalize", "gemm_bf16", "gemm_xres", "ln_rows_gemm", "ln_tail_gemm", "gemm_pp", "attention_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 

@@ -1141,6 +1141,17 @@ __global__ __launch_bounds__(256) void pack_gemm_w_kernel(const uint4 *__restric
     const int row = sr * rps + ch / cpr, c = ch % cpr;
     img[u] = W[((int64_t)row * K + (int64_t)kt * BK) * 2 / 16 + c];
 }
+// W [N rows, K] -> MFMA A-fragment images: 1-KiB block (k-step s, 32-feature sub-tile j) at (s * (N / 32) + j) * 1024, lane (r, h)'s
+// 16 bytes = W[32 j + r][16 s + 8 h .. + 8).  Two consecutive k-steps (24 KiB at N = 384) are ln_rows_gemm_kernel's W region of a
+// 32-k tile — LDS-DMA copies it verbatim, a fragment read is lane-linear (conflict-free, one address register) — and
+// ln_tail_gemm_kernel loads the same blocks straight into registers, one contiguous KiB per load.
+__global__ __launch_bounds__(256) void pack_frag_w_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ img, int N, int K) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte unit of the image
+    if (u >= (int64_t)N * K / 8) return;
+    const int lane = (int)(u & 63), blk = (int)(u >> 6);
+    const int nt = N / 32, s = blk / nt, j = blk % nt, r = lane & 31, h = lane >> 5;
+    img[u] = W[((int64_t)(32 * j + r) * K + 16 * s + 8 * h) / 8];
+}
 // W1 [F, 384] -> per 32-row chunk the K1-style LDS image: row rr, 16-byte slot c holds source chunk c ^ (rr & 15) (low 4 bits)
 __global__ __launch_bounds__(256) void pack_ffn_w1_kernel(const uint4 *__restrict__ W, uint4 *__restrict__ img, int F) {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;      // 16-byte unit of the image
@@ -1522,9 +1533,9 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][4 * gq + e] = bv[e];
         }
-    // LDS image of a region (as gemm_bf16_kernel at BK = 32, so pack_gemm_w_kernel(.., 384, 32, K) images fit): rows of 64 B,
-    // four to a 256-byte super-row; 16-byte slot (sr, chp) holds chunk ch = chp ^ (sr & 15) of the super-row = chunk ch & 3 of
-    // row 4 sr + (ch >> 2).  The permutation goes on the SOURCE address (LDS-DMA writes lane-linearly).
+    // LDS image of the X region (as gemm_bf16_kernel at BK = 32): rows of 64 B, four to a 256-byte super-row; 16-byte slot (sr, chp)
+    // holds chunk ch = chp ^ (sr & 15) of the super-row = chunk ch & 3 of row 4 sr + (ch >> 2).  The permutation goes on the SOURCE
+    // address (LDS-DMA writes lane-linearly).  The W region is the tile's 24 fragment blocks (pack_frag_w_kernel), copied verbatim.
     const char *xsrc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1546,19 +1557,16 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
         for (int i = 2; i < PPW; ++i)
             glds16(wsrc + (int64_t)k2 * LR_WBYTES + (wave + i * NW - XP) * 1024, dst + (wave + i * NW) * 1024);
     };
-    // fragment read addresses inside a stage: row rho, k-step s, lane half h -> super-row rho >> 2, chunk (rho & 3) * 4 + 2 s + h.
-    // X rows of this wave: rho = 32 wave + r.  W rows of tile t: rho = 32 t + r: the super-row is 8 t + (r >> 2), whose low four
-    // bits depend on the parity of t only -> two address registers per k-step and an immediate of t * 2048.
+    // fragment read addresses inside a stage.  X: row rho = 32 wave + r, k-step s, lane half h -> super-row rho >> 2, chunk
+    // (rho & 3) * 4 + 2 s + h.  W: block 12 s + t of the region, this lane's 16 bytes: one address register and an immediate.
     const uint32_t lbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
-    uint32_t xo[2], wo[2][2];
+    uint32_t xo[2];
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
         const int ch = (r & 3) * 4 + 2 * sk + h;
         xo[sk] = lbase + wave * 2048 + (r >> 2) * 256 + ((ch ^ ((((wave & 1) << 3) + (r >> 2)) & 15)) << 4);
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-            wo[sk][par] = lbase + XBYTES + (r >> 2) * 256 + ((ch ^ (((par << 3) + (r >> 2)) & 15)) << 4);
     }
+    const uint32_t wl = lbase + XBYTES + lane * 16;
 
     static_assert(LR_NST >= 3 && (LR_NST - 2) * PPW <= 63, "ring depth");
 #pragma unroll
@@ -1576,11 +1584,10 @@ __global__ __launch_bounds__(NW * 64) void ln_rows_gemm_kernel(const bf16_t *__r
         const uint32_t so = stage * STAGE;
         lds_read_b128_imm<0>(bfr[0], xo[0] + so);
         lds_read_b128_imm<0>(bfr[1], xo[1] + so);
-        const uint32_t a00 = wo[0][0] + so, a01 = wo[0][1] + so, a10 = wo[1][0] + so, a11 = wo[1][1] + so;
-        auto rd = [&](auto nc) __attribute__((always_inline)) {            // read n: k-step n / 12, tile n % 12
+        const uint32_t wa = wl + so;
+        auto rd = [&](auto nc) __attribute__((always_inline)) {            // read n: k-step n / 12, tile n % 12 = block n
             constexpr int n = decltype(nc)::value;
-            constexpr int sk = n / 12, t = n % 12;
-            lds_read_b128_imm<t * 2048>(fr[n % (PF + 1)], sk == 0 ? ((t & 1) ? a01 : a00) : ((t & 1) ? a11 : a10));
+            lds_read_b128_imm<n * 1024>(fr[n % (PF + 1)], wa);
         };
         ff_static_for(std::make_integer_sequence<int, PF>{}, rd);
         ff_static_for(std::make_integer_sequence<int, NRD>{}, [&](auto nc) __attribute__((always_inline)) {
@@ -1967,7 +1974,7 @@ struct tsim_encoder {
         bf16_t *wqkv, *wo, *w1, *w2;
         bf16_t *pqkv = nullptr, *po = nullptr, *p1 = nullptr, *p2 = nullptr;     // tile-major copies for the ping-pong GEMM
         bf16_t *lo = nullptr, *l2 = nullptr;   // H = 384: O-proj / FFN2 weights as the k-tile LDS images of the LayerNorm GEMM
-        bf16_t *lo32 = nullptr, *l232 = nullptr;   // ... and as 32-k images for ln_rows_gemm_kernel
+        bf16_t *lo32 = nullptr, *l232 = nullptr;   // ... and as MFMA fragment images (pack_frag_w_kernel) for ln_rows_gemm / ln_tail_gemm
         uint8_t *qqkv = nullptr, *qo = nullptr, *q1 = nullptr, *q2 = nullptr;   // MXFP8 weights: e4m3 bytes (tile-major) ...
         uint8_t *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;   // ... and E8M0 block scales [out, in/32]
         float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
@@ -2147,6 +2154,181 @@ static int ffn_fused(const bf16_t *X, const bf16_t *W1img, const bf16_t *W2img, 
     return TSIM_OK;
 }
 
+// =====================================================================================================
+// ln_tail_gemm: the LayerNorm GEMM of width 384 for FEW rows (the remainder behind ln_rows_gemm's whole rounds, and small batches).
+//
+// A remainder launch has far fewer workgroups than CUs, and every workgroup has to see ALL of W whatever its token count: its cost is
+// the latency of its k loop.  Through an LDS ring that loop paid, per 64-k tile, a workgroup barrier, seven LDS-DMA issues per wave
+// (~100-150 cycles each) and the DMA's own latency for twelve MFMAs per wave: 1.7 us per tile, 40 us for FFN2's 24 tiles and 1 657
+// rows (against 90 us for the 65 536 rows of the main launch) — 13 % of a MiniLM forward for 2.5 % of its rows.
+// Here nothing is shared, so nothing goes through LDS: a workgroup is 32 token rows x 4 waves, wave w owns features 96 w .. + 95
+// (three accumulator tiles) and streams ITS slice of W straight from L2 into MFMA A fragments, and the token rows likewise into B
+// fragments (the four waves read the same rows: L1 hits).  W is stored as MFMA fragment blocks (pack_frag_w_kernel): a wave's load
+// is one contiguous KiB — and the image is the one ln_rows_gemm has just streamed through every XCD's L2.  (Reading a swizzled
+// LDS image instead, 16-byte chunks scattered over 2 KiB per load, measured 38 us against 27 for FFN2's remainder.)  Loads roll PF
+// k-steps ahead of their MFMAs with counted vmcnt waits; no barrier until the LayerNorm statistics cross the four feature waves (gemm_bf16_kernel's direct
+// epilogue, operation for operation).
+// Same arithmetic as the other two forms — accumulators start from the bias, k ascending in 32x32x16 steps, statistics in the order
+// (wave's 48 values, half-wave partner, waves 0..3) — so a row has the same bits whichever kernel produced it.
+// Bound: 12 KiB of W + 4 KiB of rows per k-step and workgroup at the CU's 64 B/clk L2 path = 256 cycles per k-step.
+// =====================================================================================================
+typedef __attribute__((ext_vector_type(4))) uint32_t lt_u32x4;
+constexpr int LT_PF = 12;   // k-steps in flight (4 loads each: vmcnt <= 63 allows 16; K / 16 must be a multiple)
+template <int PF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ln_tail_gemm_kernel(
+    const bf16_t *__restrict__ X, const bf16_t *__restrict__ Wimg32, const float *__restrict__ bias, const bf16_t *__restrict__ res,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float eps, bf16_t *__restrict__ out, int M, int K, int xpacked) {
+    constexpr int N = 384, NT = 3, WAVES_N = 4, BM = 32;
+    __shared__ float red[2 * WAVES_N * BM];
+    const int lane = threadIdx.x & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int ksteps = K / 16;                                   // a multiple of PF (launcher)
+
+    // per-lane source addresses at k-step 0; per k-step the W pointer advances 12 KiB, the row pointer 1 KiB (packed) or 32 B
+    const int64_t mrow = (int64_t)(m0 + r < M ? m0 + r : M - 1);
+    const char *xp = reinterpret_cast<const char *>(X) +
+                     (xpacked ? (int64_t)(m0 >> 5) * K * 64 + h * 512 + r * 16          // (rows of a partial block exist: padding)
+                              : (mrow * K + 8 * h) * 2);
+    const int xstep = xpacked ? 1024 : 32;
+    const char *wp = reinterpret_cast<const char *>(Wimg32) + (int64_t)(NT * wn) * 1024 + lane * 16;
+    constexpr int WSTEP = (N / 32) * 1024;                       // fragment blocks of one k-step
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float4 bv = *reinterpret_cast<const float4 *>(bias + wn * 96 + 4 * h + i * 32 + 8 * gq);
+            acc[i][4 * gq + 0] = bv.x;
+            acc[i][4 * gq + 1] = bv.y;
+            acc[i][4 * gq + 2] = bv.z;
+            acc[i][4 * gq + 3] = bv.w;
+        }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(acc[i]));   // retire the bias loads: the vmcnt counts below are exact
+
+    lt_u32x4 fw[PF][NT], fx[PF];
+    // (the three W loads of a step use immediate offsets 0 / 1024 / 2048 from one address register)
+    auto issue = [&](auto slotc, int s) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value;
+        const int sc = s < ksteps ? s : ksteps - 1;              // past the end: re-read the last step (uniform vmcnt)
+        const char *w = wp + (int64_t)sc * WSTEP;
+        const char *x = xp + (int64_t)sc * xstep;
+        // (references: an asm operand alone does not make a generic lambda capture the arrays)
+        lt_u32x4 &f0 = fw[slot][0], &f1 = fw[slot][1], &f2 = fw[slot][2], &f3 = fx[slot];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f0) : "v"(w) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(f1) : "v"(w) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(f2) : "v"(w) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f3) : "v"(x) : "memory");
+    };
+    ff_static_for(std::make_integer_sequence<int, PF>{}, [&](auto sc) __attribute__((always_inline)) { issue(sc, decltype(sc)::value); });
+    for (int s0 = 0; s0 < ksteps; s0 += PF) {
+        ff_static_for(std::make_integer_sequence<int, PF>{}, [&](auto sc) __attribute__((always_inline)) {
+            constexpr int slot = decltype(sc)::value;
+            // the 4 (PF - 1) loads of the PF - 1 younger steps may stay in flight
+            lt_u32x4 &f0 = fw[slot][0], &f1 = fw[slot][1], &f2 = fw[slot][2], &f3 = fx[slot];
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(4 * (PF - 1)) : "memory");
+            const bf16x8 bx = __builtin_bit_cast(bf16x8, f3);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0), bx, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1), bx, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f2), bx, acc[2], 0, 0, 0);
+            // the slot's registers are free once the MFMAs have READ them: the reload below is ordered behind them by its
+            // dependency on the same registers
+            asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));
+            issue(sc, s0 + slot + PF);
+        });
+    }
+    wait_vmcnt<0>();
+
+    // ---- epilogue: gemm_bf16_kernel<.., WAVES_N = 4, ..>'s direct form with MT = 1, operation for operation
+    const int nbase = wn * 96 + 4 * h;
+    {
+        const int64_t m = m0 + r;
+        const int64_t mr = m < M ? m : M - 1;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq += 2) {
+                const uint4 o = *reinterpret_cast<const uint4 *>(res + mr * N + wn * 96 + i * 32 + 8 * gq + 8 * h);
+                auto s0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+                const uint32_t a0 = s0[0], c0 = s0[1], a1 = s1[0], c1 = s1[1];
+                acc[i][4 * gq + 0] += __uint_as_float(a0 << 16);
+                acc[i][4 * gq + 1] += __uint_as_float(a0 & 0xffff0000u);
+                acc[i][4 * gq + 2] += __uint_as_float(a1 << 16);
+                acc[i][4 * gq + 3] += __uint_as_float(a1 & 0xffff0000u);
+                acc[i][4 * gq + 4] += __uint_as_float(c0 << 16);
+                acc[i][4 * gq + 5] += __uint_as_float(c0 & 0xffff0000u);
+                acc[i][4 * gq + 6] += __uint_as_float(c1 << 16);
+                acc[i][4 * gq + 7] += __uint_as_float(c1 & 0xffff0000u);
+            }
+    }
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (pass == 0) {
+                    s += acc[i][g];
+                } else {
+                    const float dlt = acc[i][g] - mean;
+                    s = fmaf(dlt, dlt, s);
+                }
+            }
+        s += __shfl_xor(s, 32, 64);
+        if (h == 0) red[(pass * WAVES_N + wn) * BM + r] = s;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) t += red[(pass * WAVES_N + w) * BM + r];
+        if (pass == 0)
+            mean = t / (float)N;
+        else
+            rstd = 1.0f / sqrtf(t / (float)N + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        float4 gv[4], be[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            gv[gq] = *reinterpret_cast<const float4 *>(gamma + nbase + i * 32 + 8 * gq);
+            be[gq] = *reinterpret_cast<const float4 *>(beta + nbase + i * 32 + 8 * gq);
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const float y0 = fmaf((acc[i][4 * gq + 0] - mean) * rstd, gv[gq].x, be[gq].x);
+            const float y1 = fmaf((acc[i][4 * gq + 1] - mean) * rstd, gv[gq].y, be[gq].y);
+            const float y2 = fmaf((acc[i][4 * gq + 2] - mean) * rstd, gv[gq].z, be[gq].z);
+            const float y3 = fmaf((acc[i][4 * gq + 3] - mean) * rstd, gv[gq].w, be[gq].w);
+            pk[2 * gq] = pack_bf16x2(y0, y1);
+            pk[2 * gq + 1] = pack_bf16x2(y2, y3);
+        }
+        const int64_t m = m0 + r;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq += 2) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gq], pk[2 * gq + 2], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gq + 1], pk[2 * gq + 3], false, false);
+            if (m < M)
+                *reinterpret_cast<uint4 *>(out + m * N + wn * 96 + i * 32 + 8 * gq + 8 * h) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    }
+}
+
+static int ln_tail_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias, const bf16_t *res, const float *gamma,
+                        const float *beta, float eps, bf16_t *out, int M, int K, hipStream_t st, bool xpacked) {
+    if (K % (16 * LT_PF) != 0) return fail(TSIM_EUNSUPPORTED, "ln_tail_gemm: K=%d", K);
+    hipLaunchKernelGGL(ln_tail_gemm_kernel<LT_PF>, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, st, X, Wimg32, bias, res, gamma, beta,
+                       eps, out, M, K, xpacked ? 1 : 0);
+    TSIM_HIP_CHECK(hipGetLastError());
+    return TSIM_OK;
+}
+
 // LayerNorm GEMM of width 384 over rows [0, M) in workgroups of NW * 32 token rows (the last one may be partial)
 template <int NW, int NST, bool STAG = false>
 static int ln_rows_gemm(const bf16_t *X, const bf16_t *Wimg32, const float *bias, const bf16_t *res, const float *gamma,
@@ -2231,6 +2413,11 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                     X += (int64_t)m1 * K; res += (int64_t)m1 * N; out += (int64_t)m1 * N; M -= m1;
                     after_rows = true;
                 }
+                // few rows (a remainder, or a small batch): one round of 32-row workgroups that stream W straight into registers
+                static int frag_tail = -1;
+                if (frag_tail < 0) { const char *e = getenv("TSIM_LN_TAIL_FRAG"); frag_tail = e ? atoi(e) : 1; }
+                if (frag_tail && M <= 256 * 32 && K % (16 * LT_PF) == 0)
+                    return ln_tail_gemm(X, Wimg32, bias, res, gamma, beta, eps, out, M, K, st, xpacked);
                 // a remainder of at most 128 workgroups of 64 rows: the deep-ring form (TSIM_LN_ROWS_TAIL=0: the 64- / 32-token
                 // tiles of gemm_bf16_kernel below)
                 static int rows_tail = -1;
@@ -2350,10 +2537,10 @@ extern "C" int tsim_encoder_create(const tsim_encoder_config *cfg, const tsim_en
                                reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l2), 384, 64, F);
             if ((rc = dev_alloc(e, (size_t)H * H * 2, (void **)&d.lo32))) return bail(rc);
             if ((rc = dev_alloc(e, (size_t)H * F * 2, (void **)&d.l232))) return bail(rc);
-            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * H / 8 + 255) / 256)), dim3(256), 0, 0,
-                               reinterpret_cast<const uint4 *>(d.wo), reinterpret_cast<uint4 *>(d.lo32), 384, 32, H);
-            hipLaunchKernelGGL(pack_gemm_w_kernel, dim3((unsigned)((H * F / 8 + 255) / 256)), dim3(256), 0, 0,
-                               reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l232), 384, 32, F);
+            hipLaunchKernelGGL(pack_frag_w_kernel, dim3((unsigned)((H * H / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.wo), reinterpret_cast<uint4 *>(d.lo32), 384, H);
+            hipLaunchKernelGGL(pack_frag_w_kernel, dim3((unsigned)((H * F / 8 + 255) / 256)), dim3(256), 0, 0,
+                               reinterpret_cast<const uint4 *>(d.w2), reinterpret_cast<uint4 *>(d.l232), 384, F);
             if (hipGetLastError() != hipSuccess) return bail(fail(TSIM_EHIP, "LayerNorm GEMM weight packing failed"));
         }
         if (!mx && H == 384 && F % 64 == 0 && F <= 4096) {   // fused FFN (ffn_fused_kernel): both matrices as LDS images

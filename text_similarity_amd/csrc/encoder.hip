@@ -823,7 +823,16 @@ __device__ __forceinline__ void ff_static_for(std::integer_sequence<int, I...>, 
 // stores at the end of the step.  The bias is not added in the epilogue: the accumulators START from it.
 // Same k order per output as gemm_xres_kernel (ascending), so rows stay batch-invariant bit for bit.
 // =====================================================================================================
-constexpr int X2_BN = 96, X2_BK = 128, X2_NSTAGE = 3, X2_KG = 3, X2_NSUB = 3;
+// TWO STEPS PER BARRIER (TSIM_X2_PAIR).  Stamps (tools/x2_stamps.py): of a step's ~3 200 cycles a wave spends ~1 000 in the ring wait
+// + workgroup barrier and both waves of a SIMD sit there together — a cost per BARRIER, not per MFMA.  With six ring slots the
+// tiles are synchronised in pairs: one vmcnt wait + barrier in front of every even step covers the tiles of steps st and st + 1
+// (both issued four steps earlier), the odd step runs straight on; a step issues the tile of step st + 4 into the slot the pair
+// before the current one has left (everyone is past that pair: they passed this pair's barrier).
+// MEASURED: QKV 73.1 -> 71.2 us, FFN1 119.6 -> 115.3 us (-3 %): the wait is mostly not a per-barrier constant.
+#ifndef TSIM_X2_PAIR
+#define TSIM_X2_PAIR 1
+#endif
+constexpr int X2_BN = 96, X2_BK = 128, X2_NSTAGE = TSIM_X2_PAIR ? 6 : 3, X2_PD = TSIM_X2_PAIR ? 4 : 2, X2_KG = 3, X2_NSUB = 3;
 
 template <int EPI, bool PK>   // PK: the output goes out in the block-packed layout (see packed_off)
 __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
@@ -879,8 +888,10 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
     int cur_mb = -1, m0 = 0;
     f32x16 accA[X2_NSUB], accB[X2_NSUB];
     int old_m0 = 0, old_n0 = 0;
-    int st = 0;                       // steps done: ring position
+    int st = 0;                       // steps done
+    int ring = 0;                     // st % X2_NSTAGE, kept as a counter
     int young1 = 0, young2 = 0;       // global stores issued in the previous step / the one before (-1: unknown)
+    [[maybe_unused]] int young3 = 0;  // ... and the one before that (pairs)
 
     // epilogue of ONE finished sub-tile whose 16 registers have been packed into pk[8] (pk[2gq], pk[2gq+1] = the lane's four
     // features 8gq + 4h .. +3 of group gq): swap half-waves so that every lane owns 8 contiguous features, two 16-byte stores
@@ -908,7 +919,15 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
         const uint64_t ob = out_base;   // (an asm operand alone does not make a generic lambda capture the variable)
 #if !(defined(TSIM_X2_DIAG) && (TSIM_X2_DIAG & 1))   // (bit 1: TIMING-ONLY, no output stores)
         if (full || mrow0 + r < M)
+            // (s_nop: a store of more than 64 bits needs one wait state before a VALU may overwrite its data registers; hipcc
+            // pads its own stores but cannot see into an asm statement — without it the next instruction now and then replaced the
+            // data under the store: a corrupted 16-byte group, non-finite rows after the LayerNorm, the whole sequence after the
+            // next attention, in ~20 % of the forwards on some boxes and none on others)
+#ifdef TSIM_X2_DIAG_NO_STORE_NOP   // (control build for tools/nan_probe.py: the fault as it was)
             asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(o), "s"(ob) : "memory");
+#else
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(o), "s"(ob) : "memory");
+#endif
 #else
         asm volatile("" ::"v"(voff), "v"(o));
 #endif
@@ -921,8 +940,8 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
         return pack_bf16x2(y0, y1);
     };
 
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int i = 0; i < X2_PD; ++i) issue(i, i);
     [[maybe_unused]] unsigned x2_n = 0, x2_w = 0, x2_c = 0, x2_e = 0;   // (diagnostic build only; 32-bit sums: a workgroup runs < 2^32 cycles)
     auto run_item = [&](f32x16 (&cur)[X2_NSUB], f32x16 (&old)[X2_NSUB], int item, auto with_old) __attribute__((always_inline)) {
         constexpr bool OLD = decltype(with_old)::value;
@@ -934,23 +953,29 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             for (int s = 0; s < KSTEPS; ++s) bx[s] = *reinterpret_cast<const bf16x8 *>(xp + 16 * s);
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(bx[s]));   // retire these ordinary loads here
-            young1 = young2 = 0;                              // ... and with them (vmcnt(0)) everything older
+            young1 = young2 = young3 = 0;                     // ... and with them (vmcnt(0)) everything older
         }
         const int n0 = (item % ntiles) * X2_BN;
         // accumulators start from the bias: cur[i][q] belongs to feature n0 + 32 i + (q & 3) + 8 (q >> 2) + 4 h
-#pragma unroll
-        for (int i = 0; i < X2_NSUB; ++i) {
+        // (ONE address register + immediates: twelve separately computed addresses were hoisted out of the loop and spilled)
+        const uint32_t baddr = bias_lds + (n0 + 4 * h) * 4;
+        ff_static_for(std::make_integer_sequence<int, X2_NSUB>{}, [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
             f32x4 bv[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(bv[gq]) : "v"(bias_lds + (n0 + i * 32 + 4 * h + 8 * gq) * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[0]) : "v"(baddr), "n"((i * 32 + 0) * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[1]) : "v"(baddr), "n"((i * 32 + 8) * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[2]) : "v"(baddr), "n"((i * 32 + 16) * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[3]) : "v"(baddr), "n"((i * 32 + 24) * 4) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3])::"memory");
 #pragma unroll
             for (int q = 0; q < 16; ++q) cur[i][q] = bv[q >> 2][q & 3];
-        }
+        });
 #pragma unroll
         for (int g = 0; g < X2_KG; ++g) {
-            const int stage = st % X2_NSTAGE;
+            // (opaque on purpose: with six steps per loop trip and six slots hipcc knows the slot of every unrolled step, hoists the
+            // 6 x 8 fragment addresses out of the loop as invariants and spills all 48 of them)
+            if constexpr (TSIM_X2_PAIR) asm volatile("" : "+s"(ring));
+            const int stage = TSIM_X2_PAIR ? ring : st % X2_NSTAGE;
             [[maybe_unused]] const unsigned long long xs0 = XR_T();
             // ring wait: the tile of this step was issued two steps ago; the stores of the last two steps are younger than it
             if constexpr (TSIM_X2_EARLY_STORE) {
@@ -961,13 +986,35 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                 else if (extra == 2) wait_vmcnt<PPW + 2>();
                 else if (extra == 1) wait_vmcnt<PPW + 1>();
                 else wait_vmcnt<PPW>();
+            } else if constexpr (TSIM_X2_PAIR) {
+                // even step: the tiles of this step and the next must have landed.  Younger than the next step's pieces: the pieces
+                // of steps st + 2 and st + 3 and the stores of the last three steps
+                if ((st & 1) == 0) {
+#if defined(TSIM_X2_PAIR_DBG) && (TSIM_X2_PAIR_DBG & 4)
+                    const int ys = 0;
+#else
+                    const int ys = (young1 >= 0 && young2 >= 0 && young3 >= 0) ? young1 + young2 + young3 : 0;
+#endif
+                    if (ys == 6) wait_vmcnt<2 * PPW + 6>();
+                    else if (ys == 4) wait_vmcnt<2 * PPW + 4>();
+                    else if (ys == 2) wait_vmcnt<2 * PPW + 2>();
+                    else wait_vmcnt<2 * PPW>();               // none, or unknown store count: always safe
+#if defined(TSIM_X2_PAIR_DBG) && (TSIM_X2_PAIR_DBG & 2)
+                    wait_vmcnt<0>();
+#endif
+                    __builtin_amdgcn_s_barrier();
+                }
+#if defined(TSIM_X2_PAIR_DBG) && (TSIM_X2_PAIR_DBG & 1)
+                else __builtin_amdgcn_s_barrier();
+#endif
+                __builtin_amdgcn_sched_barrier(0);            // (the odd step has no barrier to fence hipcc's scheduler either)
             } else {
             if (young1 == 0 && young2 == 0) wait_vmcnt<PPW>();
             else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 2) wait_vmcnt<PPW + 2>();
             else if (young1 >= 0 && young2 >= 0 && young1 + young2 == 4) wait_vmcnt<PPW + 4>();
             else wait_vmcnt<PPW>();                           // unknown store count: drain (always safe)
             }
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!TSIM_X2_PAIR) __builtin_amdgcn_s_barrier();
             [[maybe_unused]] const unsigned long long xs1 = XR_T();
             // Right behind the barrier all eight waves have LDS-DMA to issue and queue at the CU's one address path while the
             // matrix pipe idles; the tile is not needed for two steps, so its three pieces are dropped between the k-steps'
@@ -976,7 +1023,8 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
 #define TSIM_X2_SPREAD 1
 #endif
             static_assert(PPW == 3, "issue schedule below places three pieces");
-            if constexpr (!TSIM_X2_SPREAD) issue(st + 2, (stage + 2) % X2_NSTAGE);
+            static_assert(!(TSIM_X2_PAIR && TSIM_X2_EARLY_STORE), "the pair form counts stores at the end of a step");
+            if constexpr (!TSIM_X2_SPREAD) issue(st + X2_PD, (stage + X2_PD) % X2_NSTAGE);
             const char *ws = smem + stage * STAGE;
             uint32_t pk[8];
 #ifndef TSIM_X2_ASMPIPE
@@ -1006,7 +1054,7 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                     cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[n % (PF + 1)]), bx[g * 8 + ks], cur[i], 0, 0, 0);
                     if constexpr (i == X2_NSUB - 1) {
                         if constexpr (TSIM_X2_SPREAD && (ks == 1 || ks == 3 || ks == 5))
-                            issue_pieces(st + 2, (stage + 2) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
+                            issue_pieces(st + X2_PD, (stage + X2_PD) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
                         if constexpr (OLD && !TSIM_X2_EARLY_STORE) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
                         if constexpr (OLD && TSIM_X2_EARLY_STORE) {
                             if constexpr (ks < 4) {
@@ -1028,7 +1076,7 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                     cur[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bx[g * 8 + ks], cur[i], 0, 0, 0);
                 }
                 if constexpr (TSIM_X2_SPREAD) {
-                    if (ks == 1 || ks == 3 || ks == 5) issue_pieces(st + 2, (stage + 2) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
+                    if (ks == 1 || ks == 3 || ks == 5) issue_pieces(st + X2_PD, (stage + X2_PD) % X2_NSTAGE, ks >> 1, (ks >> 1) + 1);
                 }
                 if constexpr (OLD) pk[ks] = finish2(old[g][2 * ks], old[g][2 * ks + 1]);   // in the MFMAs' shadow
             }
@@ -1039,6 +1087,7 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
             for (int i = 0; i < X2_NSUB; ++i) asm volatile("" : "+v"(cur[i]));
 #endif
             [[maybe_unused]] const unsigned long long xs2 = XR_T();
+            young3 = young2;
             young2 = young1;
             young1 = 0;
             if constexpr (OLD) {
@@ -1059,6 +1108,7 @@ __global__ __launch_bounds__(512) void gemm_xres2_kernel(const bf16_t *__restric
                 }
             }
             ++st;
+            ring = ring + 1 == X2_NSTAGE ? 0 : ring + 1;
 #ifdef TSIM_PP_STAMPS
             { const unsigned long long xs3 = XR_T(); x2_n += 1; x2_w += (unsigned)(xs1 - xs0); x2_c += (unsigned)(xs2 - xs1); x2_e += (unsigned)(xs3 - xs2); }
 #endif
@@ -2404,10 +2454,9 @@ static int gemm_res_ln(const bf16_t *X, const bf16_t *W, const bf16_t *Wp, const
                 const int t256 = M / 256;
                 const int use = (t256 % 256) >= 128 ? t256 : (t256 / 256) * 256;
                 if (use > 0) {
-                    static int stag = -1;
-                    if (stag < 0) { const char *e = getenv("TSIM_LN_ROWS_STAG"); stag = e ? atoi(e) : 0; }   // measured equal (68.5 vs 66-68 us per launch): off
-                    int rc = stag ? ln_rows_gemm<8, 4, true>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st, xpacked)
-                                  : ln_rows_gemm<8, 3>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st, xpacked);
+                    // (a four-slot ring with the second half of the waves issuing behind their MFMAs — STAG = true — measured equal,
+                    // 68.5 vs 66-68 us per launch; not instantiated)
+                    int rc = ln_rows_gemm<8, 3>(X, Wimg32, bias, res, gamma, beta, eps, out, use * 256, K, st, xpacked);
                     const int m1 = use * 256;
                     if (rc || m1 == M) return rc;
                     X += (int64_t)m1 * K; res += (int64_t)m1 * N; out += (int64_t)m1 * N; M -= m1;

@@ -130,7 +130,7 @@ def main() -> None:
     # encoder: HBM bytes per layer = sum over the layer's kernels (projections, attention, LayerNorm GEMMs and their remainder
     # launches) of FETCH x 2 + WRITE, over all forwards of the PMC command, divided by forwards x layers
     if a.fetch and a.write:
-        layer_kernels = ("gemm_xres", "attention_kernel", "ln_rows_gemm", "gemm_bf16_kernel", "ffn_fused", "gemm_pp", "res_ln_rows")
+        layer_kernels = ("gemm_xres", "attention_kernel", "ln_rows_gemm", "ln_tail_gemm", "gemm_bf16_kernel", "ffn_fused", "gemm_pp", "res_ln_rows")
         tot_f = sum(v * n for k, (v, n) in fe.items() if any(t in k for t in layer_kernels))
         tot_w = sum(v * n for k, (v, n) in wr.items() if any(t in k for t in layer_kernels))
         per_layer = (2 * tot_f + tot_w) * 1024 / (a.searches * a.layers)

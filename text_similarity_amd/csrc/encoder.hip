@@ -1755,7 +1755,7 @@ template <int DH, bool REL, bool PK = false>   // PK: qkv is in the block-packed
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 6 : 4))) void attention_kernel(const bf16_t *__restrict__ qkv,
                                                         const int32_t *__restrict__ cu, const int32_t *__restrict__ col,
                                                         const float *__restrict__ relb, int relw, int H,
-                                                        int heads, float scale, bf16_t *__restrict__ ctx) {
+                                                        int heads, float scale, bf16_t *__restrict__ ctx, int B, int xcd_map) {
     constexpr int KS = DH / 16;            // k-steps of the QK^T product
     constexpr int OT = (DH + 31) / 32;     // 32-row blocks of O^T
     constexpr int ROWB = DH * 2 < 64 ? 64 : DH * 2;   // bytes per key row of the V image (>= 32 dims, so block reads stay inside)
@@ -1763,7 +1763,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 32 ? 
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = blockIdx.x, head = blockIdx.y * 4 + wave, qb = blockIdx.z;
+    // XCD-aware order: workgroup b runs on XCD b % 8, so sequence = (b % 8) * ceil(B / 8) + b / 8 gives every XCD one contiguous
+    // range of sequences: neighbours in the packed token axis share cache lines (a sequence's slice of a 512-byte chunk or of a
+    // row rarely starts on a line boundary), and with the plain order the two halves of such a line were fetched by two L2s
+    int seq = blockIdx.x;
+    if (xcd_map) {
+        seq = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        if (seq >= B) return;
+    }
+    const int head = blockIdx.y * 4 + wave, qb = blockIdx.z;
     const int t0 = cu[seq], S = cu[seq + 1] - t0;
     if (qb * 32 >= S || head >= heads) return;  // wave-uniform
     const int r = lane & 31, h = lane >> 5;
@@ -2716,7 +2724,9 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
         const bool pk = !mx && !rel && use_packed_layout(H, F);
         const int32_t *col = rel ? (tok_col ? tok_col : tok_pos) : nullptr;
         const int qblocks = (max_len + 31) / 32 > 0 ? (max_len + 31) / 32 : 1;
-        const dim3 agrid((unsigned)B, (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
+        static int att_xcd = -1;
+        if (att_xcd < 0) { const char *ev = getenv("TSIM_ATT_XCD"); att_xcd = ev ? atoi(ev) : 1; }
+        const dim3 agrid((unsigned)(att_xcd ? ((B + 7) / 8) * 8 : B), (unsigned)((c.heads + 3) / 4), (unsigned)qblocks);
         for (int l = 0; l < c.num_layers; ++l) {
             const tsim_encoder::Layer &L = e->layers[l];
             if (mx) {   // projections on MXFP8 operands (v_mfma_scale_f32_32x32x64_f8f6f4); x0's image comes fused from the
@@ -2730,13 +2740,13 @@ extern "C" int tsim_encoder_forward(tsim_encoder *e, const int32_t *tok_ids, con
     do {                                                                                                       \
         if (rel)                                                                                               \
             hipLaunchKernelGGL((attention_kernel<D, true>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col,  \
-                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx, B, att_xcd);                                \
         else if (pk)                                                                                           \
             hipLaunchKernelGGL((attention_kernel<D, false, true>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col, \
-                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx, B, att_xcd);                                \
         else                                                                                                   \
             hipLaunchKernelGGL((attention_kernel<D, false>), agrid, dim3(256), 0, st, e->qkv, cu_seqlens, col, \
-                               e->relb, e->relw, H, c.heads, scale, e->ctx);                                   \
+                               e->relb, e->relw, H, c.heads, scale, e->ctx, B, att_xcd);                                \
     } while (0)
             if (dh == 16) ATT(16); else if (dh == 32) ATT(32); else ATT(64);
 #undef ATT

@@ -150,3 +150,25 @@ def test_capacity_is_checked():
     rc = _lib.lib().tsim_wordpiece_encode(wp._h, text, off.ctypes.data, 1, 64, 1, ids.ctypes.data, 4, lens.ctypes.data,
                                           handled.ctypes.data)
     assert rc == 3      # TSIM_ENOMEM: out_capacity below bytes + specials
+
+
+def test_fuzz_ascii_strings_against_the_library():
+    """Arbitrary 7-bit strings (every control character, runs of punctuation and blanks, long unbroken words): ids == library."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    vocab, _ = _piece_vocab(seed=21)
+    tok = _tok(vocab)
+    wp = NativeWordPiece.from_tokenizer(tok)
+    alphabet = st.characters(min_codepoint=0, max_codepoint=127)
+    words = st.text(alphabet=st.sampled_from("abnerthstiquxz019 .,'-[]#\t\n\x00\x1f\x7f"), max_size=40)
+
+    @settings(max_examples=150, deadline=None, database=None)
+    @given(st.lists(st.one_of(st.text(alphabet=alphabet, max_size=120), words), min_size=1, max_size=12),
+           st.sampled_from([4, 9, 64]))
+    def run(docs, max_len):
+        ref_flat, ref_lens = _tokenize_library(tok, docs, max_len, 64)
+        flat, lens = wp.tokenize_packed(docs, max_len, lambda rest: _tokenize_library(tok, rest, max_len, 64))
+        assert np.array_equal(lens, ref_lens) and np.array_equal(flat, ref_flat), docs
+
+    run()

@@ -332,6 +332,9 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
             consider(sv[u].z, iv[u].z);
             consider(sv[u].w, iv[u].w);
             if (iv[u].w < 0) continue;
+            // the list is sorted: once an entry does not beat this lane's KL-th best, nothing behind it does — and every step of
+            // the walk is a dependent memory round trip (full lists, as after phase A: 3 per list, 8 lists per lane in a row)
+            if (!key_before(sv[u].w, iv[u].w, ls[KL - 1], li[KL - 1])) continue;
             const float *lsrc = ps + (int64_t)(l0 + 64 * u) * KL;
             const int *isrc = pi + (int64_t)(l0 + 64 * u) * KL;
 #pragma unroll 1
@@ -343,7 +346,7 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
                 consider(tv.y, jv.y);
                 consider(tv.z, jv.z);
                 consider(tv.w, jv.w);
-                if (jv.w < 0) break;
+                if (jv.w < 0 || !key_before(tv.w, jv.w, ls[KL - 1], li[KL - 1])) break;
             }
         }
     }
@@ -752,9 +755,11 @@ __global__ __launch_bounds__(256) void flag_all_kernel(int64_t Q, const int *__r
 // thr_select: gthr[q] = ordered-int form of the KL-th largest of the query's P2 block maxima (pre-pass output,
 // [Q][P2] floats).  One wave per query; KL rounds of (lane-local max, wave max, owner removes one instance).
 // =====================================================================================================
+// VPL = values per lane >= P2 / 64.  (With the one 32-value form every round cost ~140 VALU instructions whatever P2 was — 20 us at
+// any Q, and four waves per SIMD share the pipe; typical P2 is 512.)
+template <int VPL>
 __global__ __launch_bounds__(256) void thr_select_kernel(const float *__restrict__ bmax, int P2, int64_t Q, int KL,
                                                          int *__restrict__ gthr) {
-    constexpr int VPL = K1_PREPASS_MAX_P2 / 64;
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -782,6 +787,14 @@ __global__ __launch_bounds__(256) void thr_select_kernel(const float *__restrict
         }
     }
     if (lane == 0) gthr[q] = best > -INFINITY ? float_to_ordered(best) : K1_GTHR_INIT;
+}
+
+static void launch_thr_select(const float *bmax, int P2, int64_t Q, int KL, int *gthr, hipStream_t st) {
+    const dim3 grid((unsigned)((Q + 3) / 4));
+    static_assert(K1_PREPASS_MAX_P2 == 2048, "dispatch below covers P2 <= 2048");
+    if (P2 <= 512) hipLaunchKernelGGL(thr_select_kernel<8>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
+    else if (P2 <= 1024) hipLaunchKernelGGL(thr_select_kernel<16>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
+    else hipLaunchKernelGGL(thr_select_kernel<32>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
 }
 
 // =====================================================================================================
@@ -1200,7 +1213,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
             const int64_t S = (int64_t)pp.nchunks * pp.rows_per_chunk;
             int rc0 = k1_launch_blockmax(pp, ld, uq, Q, uc, S, bmax, st);
             if (rc0) return rc0;
-            hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, pp.P2, Q, p.KL, gthr);
+            launch_thr_select(bmax, pp.P2, Q, p.KL, gthr, st);
             TSIM_HIP_CHECK(hipGetLastError());
         } else {
             TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
@@ -1257,7 +1270,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
         if (ok) {
             int rc0 = k1_launch_blockmax(fp, ld, uq, Q, uc, N, bmax, st);
             if (rc0) return rc0;
-            hipLaunchKernelGGL(thr_select_kernel, dim3((unsigned)((Q + 3) / 4)), dim3(256), 0, st, bmax, fp.P2, Q, k, gthr);
+            launch_thr_select(bmax, fp.P2, Q, k, gthr, st);
             TSIM_HIP_CHECK(hipGetLastError());
         }
         if (cosf)

@@ -280,28 +280,41 @@ __device__ __forceinline__ float guard_tau(float target, float eps) {
 
 // The KL best entries of a query's partial lists by (MFMA score desc, index asc): lane t < KL returns the t-th
 // (my_i = -1 when there are fewer).  ps / pi: the query's lists, nlists of KL entries each, sorted, padded with (-inf, -1).
-template <int KL, int LB = 4>
-__device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, const int *__restrict__ pi, int P2, int lane,
+// M = entries a LANE keeps (KL: all it could ever contribute).  The insertion network is the cost of this routine — the branch
+// around it is taken whenever ANY lane has an entry to insert, i.e. nearly always: 8 VALU per position and entry, ~4 000 per
+// query at KL = 16, and at Q = 4 096 the finalize kernel is VALU-throughput-bound on exactly that (45 us).  The KL winners are
+// spread over 64 lanes, so a lane almost never contributes more than a few: with M = 4 the network is a quarter.  EXACTNESS is
+// kept by a check, not by the odds: a lane's discarded entries all rank behind its M-th kept one, so they can only matter if the
+// lane had all M of its kept entries popped by the merge; in that case (returned as false) the caller repeats with M = KL.
+// (thr_update needs only a valid lower bound and never repeats.)
+template <int KL, int LB = 4, int M = KL>
+__device__ __forceinline__ bool select_kl_best(const float *__restrict__ ps, const int *__restrict__ pi, int P2, int lane,
                                                float &my_s_out, int &my_i_out) {
-    // 1a. one pass: every lane keeps the KL best of its E/64 entries in a sorted register list
-    float ls[KL];
-    int li[KL];
+    // 1a. one pass: every lane keeps the M best of its E/64 entries in a sorted register list
+    float ls[M];
+    int li[M];
 #pragma unroll
-    for (int j = 0; j < KL; ++j) {
+    for (int j = 0; j < M; ++j) {
         ls[j] = -INFINITY;
         li[j] = 0x7fffffff;
     }
+    bool dropped = false;   // this lane let go of an entry (or of the rest of a list) that it might have contributed
     auto consider = [&](float s, int i) {
-        if (i >= 0 && key_before(s, i, ls[KL - 1], li[KL - 1])) {
+        if (i >= 0) {
+            if (key_before(s, i, ls[M - 1], li[M - 1])) {
 #pragma unroll
-            for (int j = 0; j < KL; ++j) {
-                const bool ahead = key_before(s, i, ls[j], li[j]);
-                const float ns = ahead ? ls[j] : s;
-                const int ni = ahead ? li[j] : i;
-                ls[j] = ahead ? s : ls[j];
-                li[j] = ahead ? i : li[j];
-                s = ns;
-                i = ni;
+                for (int j = 0; j < M; ++j) {
+                    const bool ahead = key_before(s, i, ls[j], li[j]);
+                    const float ns = ahead ? ls[j] : s;
+                    const int ni = ahead ? li[j] : i;
+                    ls[j] = ahead ? s : ls[j];
+                    li[j] = ahead ? i : li[j];
+                    s = ns;
+                    i = ni;
+                }
+                if (M < KL && i != 0x7fffffff) dropped = true;   // a kept entry fell off the end
+            } else if (M < KL) {
+                dropped = true;
             }
         }
     };
@@ -332,9 +345,12 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
             consider(sv[u].z, iv[u].z);
             consider(sv[u].w, iv[u].w);
             if (iv[u].w < 0) continue;
-            // the list is sorted: once an entry does not beat this lane's KL-th best, nothing behind it does — and every step of
-            // the walk is a dependent memory round trip (full lists, as after phase A: 3 per list, 8 lists per lane in a row)
-            if (!key_before(sv[u].w, iv[u].w, ls[KL - 1], li[KL - 1])) continue;
+            // the list is sorted: once an entry does not beat this lane's last kept one, nothing behind it does — and every step
+            // of the walk is a dependent memory round trip (full lists, as after phase A: 3 per list, 8 lists per lane in a row)
+            if (!key_before(sv[u].w, iv[u].w, ls[M - 1], li[M - 1])) {
+                if (M < KL) dropped = true;   // (the list may go on)
+                continue;
+            }
             const float *lsrc = ps + (int64_t)(l0 + 64 * u) * KL;
             const int *isrc = pi + (int64_t)(l0 + 64 * u) * KL;
 #pragma unroll 1
@@ -346,7 +362,11 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
                 consider(tv.y, jv.y);
                 consider(tv.z, jv.z);
                 consider(tv.w, jv.w);
-                if (jv.w < 0 || !key_before(tv.w, jv.w, ls[KL - 1], li[KL - 1])) break;
+                if (jv.w < 0) break;
+                if (!key_before(tv.w, jv.w, ls[M - 1], li[M - 1])) {
+                    if (M < KL) dropped = true;
+                    break;
+                }
             }
         }
     }
@@ -354,6 +374,7 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
     // 1b. KL rounds of a 64-way merge of the list heads; the winning lane pops its head
     float my_s = -INFINITY;
     int my_i = -1;
+    int npop = 0;
     for (int t = 0; t < KL; ++t) {
         float bs = ls[0];
         int bi = li[0];
@@ -373,16 +394,19 @@ __device__ __forceinline__ void select_kl_best(const float *__restrict__ ps, con
         }
         if (li[0] == bi) {  // row ids are unique across partitions: exactly one lane owns the winner
 #pragma unroll
-            for (int j = 0; j + 1 < KL; ++j) {
+            for (int j = 0; j + 1 < M; ++j) {
                 ls[j] = ls[j + 1];
                 li[j] = li[j + 1];
             }
-            ls[KL - 1] = -INFINITY;
-            li[KL - 1] = 0x7fffffff;
+            ls[M - 1] = -INFINITY;
+            li[M - 1] = 0x7fffffff;
+            ++npop;
         }
     }
     my_s_out = my_s;
     my_i_out = my_i;
+    if constexpr (M < KL) return !__any(dropped && npop == M);
+    return true;
 }
 
 // Two-phase main pass: after the list kernel has scored the first rows of the shard (phase A: lists p2_first .. +p2_count of
@@ -398,7 +422,10 @@ __global__ __launch_bounds__(256) void thr_update_kernel(const float *__restrict
     if (q >= Q) return;
     float my_s;
     int my_i;
-    select_kl_best<KL>(part_s + (q * P2_total + p2_first) * KL, part_i + (q * P2_total + p2_first) * KL, p2_count, lane, my_s, my_i);
+    // (lanes keep four entries: should one lane hold more than four of the KL best, the KL-th of what was kept is still the score
+    // of a real row with KL - 1 others at or above it: a valid, slightly weaker bound)
+    (void)select_kl_best<KL, 4, 4>(part_s + (q * P2_total + p2_first) * KL, part_i + (q * P2_total + p2_first) * KL, p2_count, lane, my_s,
+                                   my_i);
     const float kth = __shfl(my_s, KL - 1, 64);
     const int kth_i = __shfl(my_i, KL - 1, 64);
     if (lane == 0 && kth_i >= 0) atomicMax(gthr + q, float_to_ordered(kth));   // KL rows score at least kth
@@ -441,7 +468,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB > 4 ? 1 
     my_i = lane < KL ? pi[lane] : -1;
     if (my_i < 0 && lane < KL) { my_i = (int)((q * 977 + lane * 131) % N); my_s = 0.f; }
 #else
-    select_kl_best<KL, LB>(ps, pi, P2, lane, my_s, my_i);
+    // (lanes keeping four entries + a repeat with all KL when the exactness check fails measured SLOWER here, 56-58 us against
+    // 44-49: after the main pass the lists are short and the second instantiation costs more than the smaller network saves;
+    // thr_update, whose lists are full, gains: 27 -> 16 us)
+    (void)select_kl_best<KL, LB, KL>(ps, pi, P2, lane, my_s, my_i);
 #endif
     const int nvalid = __popcll(__ballot(my_i >= 0));   // candidates sit in lanes 0 .. nvalid-1
 

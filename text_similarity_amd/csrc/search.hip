@@ -787,9 +787,12 @@ __global__ __launch_bounds__(256) void flag_all_kernel(int64_t Q, const int *__r
 // =====================================================================================================
 // VPL = values per lane >= P2 / 64.  (With the one 32-value form every round cost ~140 VALU instructions whatever P2 was — 20 us at
 // any Q, and four waves per SIMD share the pipe; typical P2 is 512.)
+// zero_base / zero_words: the call's control words and per-slot counters, cleared here instead of by a memset of their own when
+// this kernel is the one in front of the main pass (one launch and its gap less per search).
 template <int VPL>
 __global__ __launch_bounds__(256) void thr_select_kernel(const float *__restrict__ bmax, int P2, int64_t Q, int KL,
-                                                         int *__restrict__ gthr) {
+                                                         int *__restrict__ gthr, int *__restrict__ zero_base, int zero_words) {
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < zero_words; w += gridDim.x * 256) zero_base[w] = 0;
     const int lane = threadIdx.x & 63;
     const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= Q) return;
@@ -819,12 +822,13 @@ __global__ __launch_bounds__(256) void thr_select_kernel(const float *__restrict
     if (lane == 0) gthr[q] = best > -INFINITY ? float_to_ordered(best) : K1_GTHR_INIT;
 }
 
-static void launch_thr_select(const float *bmax, int P2, int64_t Q, int KL, int *gthr, hipStream_t st) {
+static void launch_thr_select(const float *bmax, int P2, int64_t Q, int KL, int *gthr, hipStream_t st, int *zero_base = nullptr,
+                              int zero_words = 0) {
     const dim3 grid((unsigned)((Q + 3) / 4));
     static_assert(K1_PREPASS_MAX_P2 == 2048, "dispatch below covers P2 <= 2048");
-    if (P2 <= 512) hipLaunchKernelGGL(thr_select_kernel<8>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
-    else if (P2 <= 1024) hipLaunchKernelGGL(thr_select_kernel<16>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
-    else hipLaunchKernelGGL(thr_select_kernel<32>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr);
+    if (P2 <= 512) hipLaunchKernelGGL(thr_select_kernel<8>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr, zero_base, zero_words);
+    else if (P2 <= 1024) hipLaunchKernelGGL(thr_select_kernel<16>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr, zero_base, zero_words);
+    else hipLaunchKernelGGL(thr_select_kernel<32>, grid, dim3(256), 0, st, bmax, P2, Q, KL, gthr, zero_base, zero_words);
 }
 
 // =====================================================================================================
@@ -1229,8 +1233,10 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
     g.flag_thr = reinterpret_cast<int *>(ws + w.flag_thr);
     g.unres_q = reinterpret_cast<int *>(ws + w.unres_q);
     g.status = out_status;
-    // ctl .. coll_cnt are contiguous: one memset clears the control words and the per-slot counters
-    TSIM_HIP_CHECK(hipMemsetAsync(ws + w.ctl, 0, w.coll_cnt + align256((size_t)Q * 4) - w.ctl, st));
+    // ctl .. coll_cnt are contiguous: one memset clears the control words and the per-slot counters — or the threshold kernel of
+    // the pre-pass does (nothing in front of it touches them)
+    const size_t ctl_bytes = w.coll_cnt + align256((size_t)Q * 4) - w.ctl;
+    bool ctl_cleared = false;
 
     bool run_collect = true;
     if (k <= TOPK_MAX_LISTS) {
@@ -1243,11 +1249,13 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
             const int64_t S = (int64_t)pp.nchunks * pp.rows_per_chunk;
             int rc0 = k1_launch_blockmax(pp, ld, uq, Q, uc, S, bmax, st);
             if (rc0) return rc0;
-            launch_thr_select(bmax, pp.P2, Q, p.KL, gthr, st);
+            launch_thr_select(bmax, pp.P2, Q, p.KL, gthr, st, reinterpret_cast<int *>(ws + w.ctl), (int)(ctl_bytes / 4));
             TSIM_HIP_CHECK(hipGetLastError());
+            ctl_cleared = true;
         } else {
             TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x80, (size_t)Q * 4, st));
         }
+        if (!ctl_cleared) TSIM_HIP_CHECK(hipMemsetAsync(ws + w.ctl, 0, ctl_bytes, st));
 #ifdef TSIM_PP_STAMPS
         if (getenv("TSIM_K1_DIAG_NOSEL"))   // DIAGNOSTIC: thresholds nothing can pass (results are wrong): the time without selection
             TSIM_HIP_CHECK(hipMemsetAsync(gthr, 0x7f, (size_t)Q * 4, st));
@@ -1295,6 +1303,7 @@ extern "C" int tsim_cosine_topk_ex(const void *eq, const float *eq_f32, int64_t 
     } else {
         // k > 28: no list kernel.  Block maxima over the whole shard give a lower bound of the k-th best MFMA score; every row
         // above (bound - margin) is collected and re-scored; widen_finalize's guard decides whether that was enough.
+        TSIM_HIP_CHECK(hipMemsetAsync(ws + w.ctl, 0, ctl_bytes, st));
         TopkPlan fp;
         const bool ok = plan_fullmax(Q, N, ld, k, &fp);
         if (ok) {
